@@ -1,0 +1,125 @@
+/* storm_hip.h -- C ABI of libstorm_hip: StORM's frequency-scan hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary under StORM's type-erased solver.  The reference has no FFI of
+ * its own; each entry point below replaces the body of one reference function/closure and is
+ * what `build.rs` + an `extern "C"` block on the Rust side would bind.
+ * All paths in comments are relative to the reference root (VincentVanlaer/StORM @ 2025-10-31).
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer; a handle owns
+ * its device memory and stream; every entry point returns 0 on success or a negative
+ * storm_status and never unwinds/aborts; storm_last_error() gives a thread-local message.
+ * Entry points taking the same handle may be called concurrently from several host threads
+ * (the reference calls its closures from rayon workers, src/dynamic_interface.rs:61-62); calls
+ * are serialised per handle.  Results preserve input order.  All floating point is IEEE f64.
+ */
+#ifndef STORM_HIP_H
+#define STORM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  STORM_OK = 0,
+  STORM_ERR_INVALID_ARGUMENT = -1,
+  STORM_ERR_HIP = -2,            /* a HIP runtime call failed (no GPU, out of memory, ...) */
+  STORM_ERR_SINGULAR = -3,       /* a collocation stage matrix was singular: the reference panics
+                                    (try_inverse().unwrap(), src/stepper.rs:88,199,250,...) */
+  STORM_ERR_NON_FINITE = -4,     /* a discriminant evaluated during refinement was not finite: the
+                                    reference panics (assert!, src/bracket.rs:209-210) */
+  STORM_ERR_CAPACITY = -5,       /* output buffer too small; *n_out holds the required count */
+  STORM_ERR_BRACKET = -6         /* ensure_maximal_bracket precondition violated (src/bracket.rs:102-112) */
+} storm_status;
+
+/* DifferenceSchemes, src/dynamic_interface.rs:24-57, in this order. */
+typedef enum {
+  STORM_COLLOC2 = 0, STORM_COLLOC4 = 1, STORM_COLLOC6 = 2, STORM_COLLOC8 = 3,
+  STORM_MAGNUS2 = 4, STORM_MAGNUS4 = 5, STORM_MAGNUS6 = 6, STORM_MAGNUS8 = 7
+} storm_scheme;
+
+typedef struct storm_solver storm_solver; /* opaque; = one ErasedSolver (src/dynamic_interface.rs:60-63) */
+
+/* = BracketResult, src/bracket.rs:6-15 (lower/upper are Point{x,f}, src/bracket.rs:63-68). */
+typedef struct {
+  double lo_x, lo_f, hi_x, hi_f, root;
+  uint64_t evals;
+} storm_bracket;
+
+/* What DiscretizedSystemImpl::new (src/system/discretized.rs:81-123) knows after interpolating
+ * the model at the collocation abscissae.  Arrays are SoA, interval-major: entry [i*p + j] is
+ * collocation point j of grid interval i, exactly the reference's `interpolated_points` /
+ * `points` order.  Host pointers, borrowed for the duration of storm_solver_create only. */
+typedef struct {
+  int32_t scheme;        /* storm_scheme */
+  uint64_t ell;          /* Rotating1D::new(ell, m), src/system/adiabatic.rs:19-24 */
+  int64_t m;
+  size_t n_int;          /* grid intervals = solver grid points - 1 */
+  size_t p;              /* collocation points per interval; must match the scheme (1,2,3,4) */
+  const double* u;       /* AdiabaticStructureCoefficients, src/system/adiabatic.rs:29-40 */
+  const double* v_gamma;
+  const double* a_star;
+  const double* c1;
+  const double* rot;
+  const double* delta_over_x; /* delta[i] / points[i*p+j], src/system/discretized.rs:107,198 */
+  double inner_c1, inner_rot; /* model point at model.inner(), used by inner_boundary (adiabatic.rs:164-168) */
+  double outer_u;             /* model point at model.outer(), used by outer_boundary (adiabatic.rs:204) */
+} storm_system_desc;
+
+/* Replaces get_solvers_inner_explicit (src/dynamic_interface.rs:193-221): builds the cached
+ * frequency-independent matrices (Rotating1D::eval, src/system/adiabatic.rs:78-114) and uploads
+ * them to the current HIP device. */
+int storm_solver_create(const storm_system_desc* desc, storm_solver** out);
+void storm_solver_destroy(storm_solver* solver);
+
+/* Replaces the `det` closure = determinant_explicit (src/dynamic_interface.rs:212,
+ * src/solver.rs:435-542), batched: det_out[k] = det(freq[k]).  Raw, unscaled discriminant; a
+ * non-finite value is returned as such (overflow parity).  Host pointers. */
+int storm_det_batch(storm_solver* solver, const double* freq, size_t n, double* det_out);
+
+/* Same with device pointers (inputs/outputs resident in HBM), asynchronous on `hip_stream`
+ * (a hipStream_t, may be NULL for the solver's own stream, in which case the call returns
+ * after the work completed). */
+int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
+
+/* Replaces ErasedSolver::scan_and_optimize (src/dynamic_interface.rs:116-160): discriminant on
+ * every grid point, sign-swap filter on adjacent points (FilterSignSwap, src/bracket.rs:236-250)
+ * dropping non-finite pairs (sets *had_invalid), then InverseQuadratic::optimize
+ * (src/bracket.rs:151-222) on every bracket with `ulp` = Precision::as_ulp() (src/bracket.rs:30-40).
+ * out[0..*n_out) in ascending bracket order.  det_out (may be NULL) receives the n scan values,
+ * index_out (may be NULL, cap entries) the grid index of each bracket's lower point. */
+int storm_scan_and_optimize(storm_solver* solver, const double* freq, size_t n, uint64_t ulp,
+                            storm_bracket* out, size_t cap, size_t* n_out, int* had_invalid,
+                            double* det_out, uint64_t* index_out);
+
+/* Replaces the `eigenvector` closure = determinant_with_upper + UpperResult::eigenvectors
+ * (src/dynamic_interface.rs:213-219, src/solver.rs:100-131,271-433), batched over modes.
+ * vec_out is [n][(n_int+1)*4], element [i*4+k] = y_{k+1}(x_i); det_out (may be NULL) is [n]. */
+int storm_eigenvector_batch(storm_solver* solver, const double* freq, size_t n, double* det_out, double* vec_out);
+
+/* Precision::Relative(p).as_ulp(), src/bracket.rs:30-40. */
+uint64_t storm_precision_relative_to_ulp(double relative_precision);
+
+/* Work counters since creation (or the last reset): discriminant evaluations (scan + refinement
+ * + single calls), of which refinement; modes whose eigenvector was computed; kernel launches. */
+typedef struct {
+  uint64_t det_evals, refine_evals, refine_rounds, eigenvectors, launches;
+} storm_stats;
+int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
+
+/* Tuning knobs; no effect on results (every path is bit-identical).
+ *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels
+ *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB) */
+int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
+
+size_t storm_solver_n_int(const storm_solver* solver);
+
+const char* storm_last_error(void);
+const char* storm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORM_HIP_H */

@@ -1,0 +1,8 @@
+"""storm_amd -- MI355X-native frequency-scan hot path of StORM behind a C ABI.
+
+The product is the shared library storm_amd/lib/libstorm_hip.so (hand-written HIP for
+gfx950, see storm_amd/csrc and include/storm_hip.h).  This package is only the thin
+ctypes binding used by the tests and the benchmark; there is no CPU fallback.
+"""
+from .ffi import (HipSolver, StormError, Bracket, SCHEMES, lib_path, load_library,  # noqa: F401
+                  relative_to_ulp)

@@ -1,0 +1,195 @@
+// mat4.hpp -- register-resident 4x4 FP64 matrices for gfx950 device code.
+//
+// Everything is fully unrolled with compile-time indices so a matrix lives in 32 VGPRs
+// and never touches scratch.  The evaluation order of every routine is part of the
+// contract: in the parity build (-ffp-contract=off) results are bit-identical to the
+// reference's nalgebra-based arithmetic (reference src/stepper.rs, src/linalg/storage.rs;
+// third-party semantics recorded in SURVEY.md 8(c)):
+//   * product: per result column, first term a pure product, then k = 1..3 ascending,
+//     term added to the running value;
+//   * inverse: cofactor expansion on the column-major entries, det from the first row
+//     of the input against the first column of cofactors, then multiply by 1/det.
+// Column-major: element (r, c) lives at v[c*4 + r].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace storm {
+
+#define SDEV __device__ __forceinline__
+
+struct M4 {
+  double v[16];
+};
+
+SDEV M4 m4_identity() {
+  M4 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.v[i] = ((i % 5) == 0) ? 1.0 : 0.0;
+  return r;
+}
+
+SDEV M4 m4_mul(const M4& a, const M4& b) {
+  M4 c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c.v[j * 4 + r] = a.v[r] * b.v[j * 4];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c.v[j * 4 + r] = a.v[k * 4 + r] * b.v[j * 4 + k] + c.v[j * 4 + r];
+    }
+  }
+  return c;
+}
+
+SDEV M4 m4_add(const M4& a, const M4& b) {
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = a.v[i] + b.v[i];
+  return c;
+}
+SDEV M4 m4_sub(const M4& a, const M4& b) {
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = a.v[i] - b.v[i];
+  return c;
+}
+SDEV M4 m4_scale(const M4& a, double s) {
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = a.v[i] * s;
+  return c;
+}
+SDEV M4 m4_neg(const M4& a) {
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = -a.v[i];
+  return c;
+}
+// I + a, I - a, a + I, a - I with the operand order of the expression they replace
+// (addition commutes bitwise, subtraction does not).
+SDEV M4 m4_eye_plus(const M4& a) {  // eye + a
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = (((i % 5) == 0) ? 1.0 : 0.0) + a.v[i];
+  return c;
+}
+SDEV M4 m4_eye_minus(const M4& a) {  // eye - a
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = (((i % 5) == 0) ? 1.0 : 0.0) - a.v[i];
+  return c;
+}
+SDEV M4 m4_minus_eye(const M4& a) {  // a - eye
+  M4 c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = a.v[i] - (((i % 5) == 0) ? 1.0 : 0.0);
+  return c;
+}
+
+// Cofactor inverse.  `ok` is false when det == 0 (the reference would panic on
+// try_inverse().unwrap()); the caller turns that into a NaN result + error flag.
+SDEV M4 m4_inverse(const M4& a, bool& ok) {
+  const double* m = a.v;
+  M4 o;
+  o.v[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
+           m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  o.v[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
+           m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  o.v[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
+           m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  o.v[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
+            m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  o.v[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
+           m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  o.v[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
+           m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  o.v[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
+           m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  o.v[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
+            m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  o.v[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
+           m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  o.v[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
+           m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  o.v[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
+            m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  o.v[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
+            m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  o.v[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
+           m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  o.v[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
+           m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  o.v[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
+            m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  o.v[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
+            m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * o.v[0] + m[1] * o.v[4] + m[2] * o.v[8] + m[3] * o.v[12];
+  ok = ok && (det != 0.0);
+  const double inv_det = 1.0 / det;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o.v[i] = o.v[i] * inv_det;
+  return o;
+}
+
+// ceil(log2(x)) from the IEEE fields, the way the reference derives its squaring count
+// (integer_decode + next_power_of_two().ilog2(), reference src/linalg/storage.rs:418-421).
+SDEV int exp_scaling_exponent(double norm) {
+  const uint64_t bits = (uint64_t)__double_as_longlong(norm);
+  const int biased = (int)((bits >> 52) & 0x7ff);
+  const uint64_t frac = bits & 0xfffffffffffffULL;
+  const uint64_t mantissa = biased == 0 ? (frac << 1) : (frac | 0x10000000000000ULL);
+  int lg = 0;
+  if (mantissa > 1) lg = 64 - __clzll((long long)(mantissa - 1));
+  return biased - 1075 + lg;
+}
+
+// exp(A) by scaling and squaring with the 18-term Taylor polynomial of Bader, Blanes &
+// Casas evaluated with 5 products (reference src/linalg/storage.rs:402-470).  The
+// polynomial terms are accumulated left to right including the zero coefficients.
+SDEV M4 m4_exp(M4 a) {
+  constexpr double T[5][5] = {
+      {0., -0.10036558103014462, -0.00802924648241157, -0.00089213849804573, 0.},
+      {0., 0.3978497494996451, 1.3678377846041172, 0.49828962252538267, -0.0006378981945947233},
+      {-10.967639605296206, 1.680158138789062, 0.05717798464788655, -0.0069821012248805206,
+       0.00003349750170860705},
+      {-0.09043168323908106, -0.06764045190713819, 0.06759613017704597, 0.029555257042931552,
+       -0.00001391802575160607},
+      {0., 0., -0.09233646193671186, -0.016936493900208172, -0.00001400867981820361}};
+  double norm = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = s + __builtin_fabs(a.v[c * 4 + r]);
+    norm = (c == 0) ? s : ((s > norm || norm != norm) ? s : norm);
+  }
+  const int exponent = exp_scaling_exponent(norm);
+  if (exponent > 0) {
+    // 2^-exponent, exact (subnormal for absurd norms, like ldexp)
+    const double sc = __builtin_ldexp(1.0, -exponent);
+    a = m4_scale(a, sc);
+  }
+  const M4 a2 = m4_mul(a, a);
+  const M4 a3 = m4_mul(a2, a);
+  const M4 a6 = m4_mul(a3, a3);
+  M4 b[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const double id = ((e % 5) == 0) ? 1.0 : 0.0;
+      b[i].v[e] = (((id * T[i][0] + a.v[e] * T[i][1]) + a2.v[e] * T[i][2]) + a3.v[e] * T[i][3]) + a6.v[e] * T[i][4];
+    }
+  }
+  const M4 a9 = m4_add(m4_mul(b[0], b[4]), b[3]);
+  M4 r = m4_add(b[1], m4_mul(m4_add(b[2], a9), a9));
+  for (int i = 0; i < exponent; ++i) r = m4_mul(r, r);
+  return r;
+}
+
+SDEV M4 m4_commutator(const M4& a, const M4& b) { return m4_sub(m4_mul(a, b), m4_mul(b, a)); }
+
+}  // namespace storm

@@ -1,0 +1,488 @@
+// storm_hip.hip -- host side of libstorm_hip: the C ABI of include/storm_hip.h.
+//
+// Owns the device-resident coefficient planes, picks a kernel path per batch, and runs the
+// bracket refinement as lock-step rounds over all brackets (each round = one batched
+// discriminant evaluation on the GPU).  No CPU fallback: without a HIP device every entry
+// point fails with STORM_ERR_HIP.
+#include "../../include/storm_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common_kernels.hpp"
+#include "scheme_kernels.hpp"
+
+namespace storm {
+
+#define STORM_DECL_SCHEME(n)                                 \
+  hipError_t launch_fused_scheme_##n(const LaunchArgs&);      \
+  hipError_t launch_build_scheme_##n(const LaunchArgs&);
+STORM_DECL_SCHEME(0) STORM_DECL_SCHEME(1) STORM_DECL_SCHEME(2) STORM_DECL_SCHEME(3)
+STORM_DECL_SCHEME(4) STORM_DECL_SCHEME(5) STORM_DECL_SCHEME(6) STORM_DECL_SCHEME(7)
+launch_fn g_launch_fused[kNumSchemes] = {launch_fused_scheme_0, launch_fused_scheme_1, launch_fused_scheme_2,
+                                         launch_fused_scheme_3, launch_fused_scheme_4, launch_fused_scheme_5,
+                                         launch_fused_scheme_6, launch_fused_scheme_7};
+launch_fn g_launch_build[kNumSchemes] = {launch_build_scheme_0, launch_build_scheme_1, launch_build_scheme_2,
+                                         launch_build_scheme_3, launch_build_scheme_4, launch_build_scheme_5,
+                                         launch_build_scheme_6, launch_build_scheme_7};
+
+static thread_local std::string g_error;
+
+struct Failure {
+  int code;
+  std::string msg;
+};
+[[noreturn]] static void fail(int code, const std::string& msg) { throw Failure{code, msg}; }
+static void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) fail(STORM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Growable device buffer.
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) hip_check(hipFree(p), "hipFree");
+    p = nullptr; cap = 0;
+    hip_check(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)), "hipMalloc");
+    cap = n;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace storm
+
+using namespace storm;
+
+struct storm_solver {
+  int device = 0;
+  int scheme = 0;
+  bool ell0 = true, uniform = true;
+  SystemDev sys{};
+  DevBuf<double> tab;
+  hipStream_t stream = nullptr;
+  DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
+  DevBuf<int> d_swaps, d_flags;
+  int path = 0;                                  // 0 auto, 1 fused, 2 split
+  size_t steps_bytes_max = size_t(4) << 30;
+  size_t fused_min_n = 32768;                    // auto: fused kernel from this batch size on
+  storm_stats stats{};
+  std::mutex mu;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = 0;
+  explicit DeviceGuard(int dev) {
+    hip_check(hipGetDevice(&prev), "hipGetDevice");
+    if (prev != dev) hip_check(hipSetDevice(dev), "hipSetDevice");
+    target = dev;
+  }
+  ~DeviceGuard() { if (prev != target) (void)hipSetDevice(prev); }
+  int target;
+};
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return STORM_OK;
+  } catch (const Failure& e) {
+    g_error = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_error = "out of host memory";
+    return STORM_ERR_HIP;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return STORM_ERR_INVALID_ARGUMENT;
+  }
+}
+
+// Frequency-independent planes: Rotating1D::eval (reference src/system/adiabatic.rs:78-114) per
+// collocation point, plus dx*c1, (dx*lambda)^2 and m*rot for add_frequency (:116-152).
+// Host arithmetic here is un-fused (this file is built with -ffp-contract=off).
+void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& uniform, double& rotm0) {
+  const size_t n_int = d.n_int, p = d.p, plane = n_int * p;
+  tab.assign(plane * kNumFields, 0.0);
+  const double ell = double(d.ell), mm = double(d.m);
+  const double lambda = ell * (ell + 1.0);
+  uniform = true;
+  rotm0 = plane ? mm * d.rot[0] : 0.0;
+  uint64_t rot_bits0;
+  std::memcpy(&rot_bits0, &rotm0, 8);
+  for (size_t i = 0; i < n_int; ++i)
+    for (size_t j = 0; j < p; ++j) {
+      const size_t src = i * p + j, dst = j * n_int + i;
+      const double dx = d.delta_over_x[src], u = d.u[src], vg = d.v_gamma[src], as = d.a_star[src];
+      double* t = tab.data();
+      t[F_M00 * plane + dst] = dx * (vg - 1.0 - ell);
+      t[F_M01 * plane + dst] = -dx * vg;
+      t[F_M10 * plane + dst] = -dx * as;
+      t[F_M11 * plane + dst] = dx * (as - u + 3.0 - ell);
+      t[F_M22 * plane + dst] = dx * (3.0 - u - ell);
+      t[F_M30 * plane + dst] = dx * (u * as);
+      t[F_M31 * plane + dst] = dx * (u * vg);
+      const double dl = dx * lambda;
+      t[F_M32 * plane + dst] = dl;
+      t[F_M33 * plane + dst] = dx * (-u + 2.0 - ell);
+      t[F_D * plane + dst] = dx;
+      t[F_DC1 * plane + dst] = dx * d.c1[src];
+      t[F_DL2 * plane + dst] = dl * dl;
+      const double rotm = mm * d.rot[src];
+      t[F_ROTM * plane + dst] = rotm;
+      uint64_t b;
+      std::memcpy(&b, &rotm, 8);
+      if (b != rot_bits0) uniform = false;
+    }
+}
+
+void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
+
+void check_flags(storm_solver* s) {
+  int flags = 0;
+  hip_check(hipMemcpyAsync(&flags, s->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, s->stream), "flags D2H");
+  hip_check(hipStreamSynchronize(s->stream), "sync");
+  if (flags & 1) {
+    hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags reset");
+    fail(STORM_ERR_SINGULAR, "singular collocation stage matrix (the reference would panic in try_inverse().unwrap())");
+  }
+}
+
+LaunchArgs make_args(storm_solver* s, const double* d_freq, size_t n, double* out, hipStream_t st) {
+  LaunchArgs a;
+  a.sys = s->sys; a.freq = d_freq; a.n = n; a.out = out; a.flags = s->d_flags.p;
+  a.ell0 = s->ell0; a.uniform = s->uniform; a.stream = st;
+  return a;
+}
+
+// Core: discriminants of n device-resident frequencies into a device buffer, on stream st.
+void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, hipStream_t st) {
+  if (n == 0) return;
+  const size_t n_int = s->sys.n_int;
+  const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
+  if (fused) {
+    hip_check(g_launch_fused[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
+    count_launch(s);
+  } else {
+    const size_t per_freq = n_int * 16 * sizeof(double);
+    size_t chunk = per_freq ? s->steps_bytes_max / per_freq : n;
+    if (chunk == 0) chunk = 1;
+    if (chunk > n) chunk = n;
+    if (chunk > 65535) chunk = 65535;  // grid.y limit
+    s->d_steps.reserve(chunk * n_int * 16);
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t m = std::min(chunk, n - off);
+      hip_check(g_launch_build[s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st)), "build_steps launch");
+      hip_check(launch_chain(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
+      count_launch(s, 2);
+    }
+  }
+  s->stats.det_evals += n;
+}
+
+void det_host(storm_solver* s, const double* freq, size_t n, double* det_out) {
+  if (n == 0) return;
+  s->d_freq.reserve(n);
+  s->d_det.reserve(n);
+  hip_check(hipMemcpyAsync(s->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
+  det_device(s, s->d_freq.p, n, s->d_det.p, s->stream);
+  hip_check(hipMemcpyAsync(det_out, s->d_det.p, n * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
+  check_flags(s);  // synchronises
+}
+
+// ---- bracketing (reference src/bracket.rs), lock-step over all brackets ----
+struct Pt { double x, f; };
+
+inline double sign_of(double f) {  // f64::signum: by sign bit, NaN stays NaN
+  if (f != f) return f;
+  return std::signbit(f) ? -1.0 : 1.0;
+}
+inline uint64_t bits_of(double x) { uint64_t b; std::memcpy(&b, &x, 8); return b; }
+inline double from_bits(uint64_t b) { double x; std::memcpy(&x, &b, 8); return x; }
+
+inline double secant(Pt a, Pt b) {  // evaluate_secant(., ., 0), src/bracket.rs:73-75
+  const double y = 0.0;
+  return (y - b.f) / (a.f - b.f) * a.x + (y - a.f) / (b.f - a.f) * b.x;
+}
+inline double inverse_quadratic(Pt a, Pt b, Pt c) {  // src/bracket.rs:77-81
+  const double y = 0.0;
+  return (y - b.f) * (y - c.f) / (a.f - b.f) / (a.f - c.f) * a.x +
+         (y - a.f) * (y - c.f) / (b.f - a.f) / (b.f - c.f) * b.x +
+         (y - a.f) * (y - b.f) / (c.f - b.f) / (c.f - a.f) * c.x;
+}
+// ensure_maximal_bracket, src/bracket.rs:96-132; true = converged (x is the root as proposed).
+inline bool clamp_proposal(double upper, double lower, double& x, uint64_t ulp) {
+  if (!(upper > lower) || !std::isfinite(upper) || !std::isfinite(lower) || !(upper >= 0.0) || !(lower >= 0.0))
+    fail(STORM_ERR_BRACKET, "bracket must satisfy 0 <= lower < upper < inf");
+  const uint64_t ub = bits_of(upper), lb = bits_of(lower);
+  if (ub - lb <= ulp) return true;
+  uint64_t xb = bits_of(x);
+  if ((ub - lb) <= 2 * ulp) xb = lb + (ub - lb) / 2;
+  else if ((ub < xb) || (ub - xb) < ulp) xb = ub - ulp;
+  else if ((lb > xb) || (xb - lb) < ulp) xb = lb + ulp;
+  x = from_bits(xb);
+  return false;
+}
+
+struct BracketState {
+  Pt lower, upper, previous;
+  bool has_prev = false, done = false;
+  double root = 0.0, pending = 0.0;
+  uint64_t evals = 0;
+};
+
+void refine_all(storm_solver* s, std::vector<BracketState>& br, uint64_t ulp) {
+  if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
+  if (!(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
+  std::vector<double> xs, fs;
+  std::vector<size_t> who;
+  for (;;) {
+    xs.clear(); who.clear();
+    for (size_t k = 0; k < br.size(); ++k) {
+      BracketState& b = br[k];
+      if (b.done) continue;
+      double x;
+      if (!b.has_prev) {
+        x = secant(b.lower, b.upper);
+      } else {
+        x = inverse_quadratic(b.lower, b.upper, b.previous);
+        if (x <= b.lower.x || x >= b.upper.x) x = secant(b.lower, b.upper);
+      }
+      if (clamp_proposal(b.upper.x, b.lower.x, x, ulp)) {
+        b.done = true; b.root = x;
+        continue;
+      }
+      b.pending = x;
+      xs.push_back(x); who.push_back(k);
+    }
+    if (xs.empty()) break;
+    fs.resize(xs.size());
+    det_host(s, xs.data(), xs.size(), fs.data());
+    s->stats.refine_evals += xs.size();
+    s->stats.refine_rounds += 1;
+    for (size_t q = 0; q < who.size(); ++q) {
+      BracketState& b = br[who[q]];
+      const Pt next{xs[q], fs[q]};
+      if (!std::isfinite(next.x) || !std::isfinite(next.f))
+        fail(STORM_ERR_NON_FINITE, "non-finite discriminant during bracket refinement");
+      b.evals += 1;
+      if (sign_of(b.upper.f) == sign_of(next.f)) { b.previous = b.upper; b.upper = next; }
+      else { b.previous = b.lower; b.lower = next; }
+      b.has_prev = true;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* storm_last_error(void) { return g_error.c_str(); }
+const char* storm_version(void) { return "storm_hip 0.1 (gfx950, parity arithmetic)"; }
+
+uint64_t storm_precision_relative_to_ulp(double rel) {
+  const double q = std::floor(rel / std::numeric_limits<double>::epsilon());
+  uint64_t u;
+  if (!(q > 0.0)) u = 0;
+  else if (q >= 18446744073709551615.0) u = UINT64_MAX;
+  else u = uint64_t(q);
+  return u < 1 ? 1 : u;
+}
+
+int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
+  if (out) *out = nullptr;
+  storm_solver* s = nullptr;
+  int rc = guarded([&] {
+    if (!d || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (d->scheme < 0 || d->scheme >= kNumSchemes) fail(STORM_ERR_INVALID_ARGUMENT, "unknown difference scheme");
+    if (d->p != size_t(scheme_points(d->scheme)))
+      fail(STORM_ERR_INVALID_ARGUMENT, "p does not match the number of collocation points of the scheme");
+    if (d->n_int > (size_t(1) << 40)) fail(STORM_ERR_INVALID_ARGUMENT, "n_int too large");
+    if (d->n_int && (!d->u || !d->v_gamma || !d->a_star || !d->c1 || !d->rot || !d->delta_over_x))
+      fail(STORM_ERR_INVALID_ARGUMENT, "null coefficient array");
+    int ndev = 0;
+    hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    if (ndev <= 0) fail(STORM_ERR_HIP, "no HIP device available");
+    s = new storm_solver();
+    hip_check(hipGetDevice(&s->device), "hipGetDevice");
+    s->scheme = d->scheme;
+    std::vector<double> tab;
+    double rotm0 = 0.0;
+    build_planes(*d, tab, s->uniform, rotm0);
+    const double ell = double(d->ell);
+    s->ell0 = (ell == 0.0);
+    if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
+    s->tab.reserve(tab.size() ? tab.size() : 1);
+    hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (!tab.empty())
+      hip_check(hipMemcpy(s->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice), "planes H2D");
+    s->d_flags.reserve(1);
+    hip_check(hipMemset(s->d_flags.p, 0, sizeof(int)), "flags memset");
+    s->sys.tab = s->tab.p;
+    s->sys.plane = d->n_int * d->p;
+    s->sys.n_int = d->n_int;
+    s->sys.ell = ell;
+    s->sys.lambda = ell * (ell + 1.0);
+    s->sys.inner_c1 = d->inner_c1;
+    s->sys.inner_rotm = double(d->m) * d->inner_rot;
+    s->sys.outer_u = d->outer_u;
+    s->sys.rotm_uniform = rotm0;
+    *out = s;
+  });
+  if (rc != STORM_OK && s) {
+    storm_solver_destroy(s);
+    if (out) *out = nullptr;
+  }
+  return rc;
+}
+
+void storm_solver_destroy(storm_solver* s) {
+  if (!s) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(s->device);
+  if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+  s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
+  s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release();
+  (void)hipSetDevice(prev);
+  delete s;
+}
+
+size_t storm_solver_n_int(const storm_solver* s) { return s ? s->sys.n_int : 0; }
+
+int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
+  return guarded([&] {
+    if (!s || !key) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    const std::string k(key);
+    if (k == "path") {
+      if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "path must be 0, 1 or 2");
+      s->path = int(value);
+    } else if (k == "steps_bytes_max") {
+      if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
+      s->steps_bytes_max = size_t(value);
+    } else if (k == "fused_min_n") {
+      if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "fused_min_n must be >= 0");
+      s->fused_min_n = size_t(value);
+    } else {
+      fail(STORM_ERR_INVALID_ARGUMENT, "unknown option: " + k);
+    }
+  });
+}
+
+int storm_solver_stats(storm_solver* s, storm_stats* out, int reset) {
+  return guarded([&] {
+    if (!s || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    *out = s->stats;
+    if (reset) s->stats = storm_stats{};
+  });
+}
+
+int storm_det_batch(storm_solver* s, const double* freq, size_t n, double* det_out) {
+  return guarded([&] {
+    if (!s || (n && (!freq || !det_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    det_host(s, freq, n, det_out);
+  });
+}
+
+int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, void* hip_stream) {
+  return guarded([&] {
+    if (!s || (n && (!d_freq || !d_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    det_device(s, d_freq, n, d_out, st);
+    if (!hip_stream) check_flags(s);
+  });
+}
+
+int storm_scan_and_optimize(storm_solver* s, const double* freq, size_t n, uint64_t ulp, storm_bracket* out,
+                            size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (n_out) *n_out = 0;
+  if (had_invalid) *had_invalid = 0;
+  return guarded([&] {
+    if (!s || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    std::vector<double> local;
+    double* dets = det_out;
+    if (!dets) { local.resize(n); dets = local.data(); }
+    det_host(s, freq, n, dets);
+    // FilterSignSwap + finite filter (src/bracket.rs:236-250, src/dynamic_interface.rs:128-138)
+    std::vector<BracketState> br;
+    std::vector<uint64_t> idx;
+    bool invalid = false;
+    for (size_t i = 0; i + 1 < n; ++i) {
+      const double a = dets[i], b = dets[i + 1];
+      if (sign_of(a) != sign_of(b)) {
+        if (std::isfinite(a) && std::isfinite(b)) {
+          BracketState st;
+          st.lower = Pt{freq[i], a};
+          st.upper = Pt{freq[i + 1], b};
+          br.push_back(st);
+          idx.push_back(i);
+        } else {
+          invalid = true;
+        }
+      }
+    }
+    if (had_invalid) *had_invalid = invalid ? 1 : 0;
+    *n_out = br.size();
+    if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+    for (const BracketState& b : br)
+      if (!std::isfinite(b.lower.x) || !std::isfinite(b.upper.x))
+        fail(STORM_ERR_BRACKET, "non-finite scan frequency");
+    refine_all(s, br, ulp);
+    for (size_t k = 0; k < br.size(); ++k) {
+      out[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f, br[k].root, br[k].evals};
+      if (index_out) index_out[k] = idx[k];
+    }
+  });
+}
+
+int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, double* det_out, double* vec_out) {
+  return guarded([&] {
+    if (!s || (n && (!freq || !vec_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    const size_t n_int = s->sys.n_int;
+    const size_t len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+    const size_t per_mode = (n_int * 16 + ustride + len) * sizeof(double);
+    size_t chunk = s->steps_bytes_max / per_mode;
+    if (chunk == 0) chunk = 1;
+    if (chunk > n) chunk = n;
+    if (chunk > 65535) chunk = 65535;
+    s->d_freq.reserve(chunk); s->d_det.reserve(chunk);
+    s->d_steps.reserve(chunk * n_int * 16 + 16);
+    s->d_upper.reserve(chunk * ustride);
+    s->d_vec.reserve(chunk * len);
+    s->d_swaps.reserve(chunk * 2);
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t m = std::min(chunk, n - off);
+      hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
+      hip_check(g_launch_build[s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
+      hip_check(launch_eigen(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p, s->d_swaps.p, s->d_det.p,
+                             s->d_vec.p, s->stream), "eigen launch");
+      count_launch(s, 3);
+      hip_check(hipMemcpyAsync(vec_out + off * len, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
+      if (det_out)
+        hip_check(hipMemcpyAsync(det_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
+      check_flags(s);
+      s->stats.eigenvectors += m;
+    }
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""ctypes binding of include/storm_hip.h (libstorm_hip.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SCHEMES = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magnus6", "magnus8"]
+_dp = C.POINTER(C.c_double)
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libstorm_hip.so")
+
+
+class StormError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"storm_hip error {code}: {msg}")
+        self.code = code
+
+
+class Bracket(C.Structure):
+    _fields_ = [("lo_x", C.c_double), ("lo_f", C.c_double), ("hi_x", C.c_double), ("hi_f", C.c_double),
+                ("root", C.c_double), ("evals", C.c_uint64)]
+
+
+class SystemDesc(C.Structure):
+    _fields_ = [("scheme", C.c_int32), ("ell", C.c_uint64), ("m", C.c_int64), ("n_int", C.c_size_t),
+                ("p", C.c_size_t), ("u", _dp), ("v_gamma", _dp), ("a_star", _dp), ("c1", _dp), ("rot", _dp),
+                ("delta_over_x", _dp), ("inner_c1", C.c_double), ("inner_rot", C.c_double),
+                ("outer_u", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("det_evals", C.c_uint64), ("refine_evals", C.c_uint64), ("refine_rounds", C.c_uint64),
+                ("eigenvectors", C.c_uint64), ("launches", C.c_uint64)]
+
+
+# every symbol include/storm_hip.h declares
+EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "storm_det_batch_device",
+           "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
+           "storm_solver_stats", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
+           "storm_version"]
+
+_lib = None
+
+
+def load_library():
+    """Load libstorm_hip.so; raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `make -C storm_amd/csrc` "
+                          "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.storm_last_error.restype = C.c_char_p
+    L.storm_version.restype = C.c_char_p
+    L.storm_solver_create.argtypes = [C.POINTER(SystemDesc), C.POINTER(C.c_void_p)]
+    L.storm_solver_destroy.argtypes = [C.c_void_p]
+    L.storm_solver_destroy.restype = None
+    L.storm_det_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp]
+    L.storm_det_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.storm_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_uint64, C.POINTER(Bracket), C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
+    L.storm_eigenvector_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp]
+    L.storm_precision_relative_to_ulp.restype = C.c_uint64
+    L.storm_precision_relative_to_ulp.argtypes = [C.c_double]
+    L.storm_solver_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L.storm_solver_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.storm_solver_n_int.restype = C.c_size_t
+    L.storm_solver_n_int.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise StormError(rc, load_library().storm_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def relative_to_ulp(rel):
+    return int(load_library().storm_precision_relative_to_ulp(rel))
+
+
+class HipSolver:
+    """One storm_solver handle.  `system` is the dict of SoA arrays + boundary scalars described by
+    storm_system_desc (what DiscretizedSystemImpl::new knows after interpolating the model)."""
+
+    def __init__(self, scheme, ell, m, system, n_int, p):
+        L = load_library()
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        arrs = {k: _f64(system[k]) for k in ("u", "v_gamma", "a_star", "c1", "rot", "delta_over_x")}
+        for k, a in arrs.items():
+            if a.size != n_int * p:
+                raise ValueError(f"{k}: expected {n_int * p} entries, got {a.size}")
+        d = SystemDesc(scheme, ell, m, n_int, p, *[_p(arrs[k]) for k in ("u", "v_gamma", "a_star", "c1", "rot",
+                                                                          "delta_over_x")],
+                       float(system["inner_c1"]), float(system["inner_rot"]), float(system["outer_u"]))
+        h = C.c_void_p()
+        _check(L.storm_solver_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.n_int, self.p, self.scheme = n_int, p, scheme
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().storm_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _check(load_library().storm_solver_set_option(self._h, key.encode(), int(value)))
+
+    def stats(self, reset=False):
+        s = Stats()
+        _check(load_library().storm_solver_stats(self._h, C.byref(s), 1 if reset else 0))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def det(self, freqs):
+        f = _f64(np.atleast_1d(freqs))
+        out = np.empty(f.size)
+        _check(load_library().storm_det_batch(self._h, _p(f), f.size, _p(out)))
+        return out
+
+    def det_device(self, d_freq_ptr, n, d_out_ptr, stream=None):
+        _check(load_library().storm_det_batch_device(self._h, C.c_void_p(d_freq_ptr), n, C.c_void_p(d_out_ptr),
+                                                    C.c_void_p(stream) if stream else None))
+
+    def scan_and_optimize(self, freqs, ulp, cap=None):
+        f = _f64(freqs)
+        cap = max(1, f.size) if cap is None else cap
+        out = (Bracket * max(cap, 1))()
+        idx = (C.c_uint64 * max(cap, 1))()
+        dets = np.empty(f.size)
+        n_out = C.c_size_t(0)
+        inv = C.c_int(0)
+        _check(load_library().storm_scan_and_optimize(self._h, _p(f), f.size, ulp, out, cap, C.byref(n_out),
+                                                      C.byref(inv), _p(dets), idx))
+        res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
+                    index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
+        return res, dets, bool(inv.value)
+
+    def eigenvector(self, freqs):
+        f = _f64(np.atleast_1d(freqs))
+        dets = np.empty(f.size)
+        vec = np.empty((f.size, (self.n_int + 1) * 4))
+        _check(load_library().storm_eigenvector_batch(self._h, _p(f), f.size, _p(dets), _p(vec)))
+        return dets, vec
