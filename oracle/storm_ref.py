@@ -51,6 +51,7 @@ def lib():
         L.sref_model_len.restype = C.c_size_t
         L.sref_model_len.argtypes = [C.c_void_p]
         L.sref_model_get.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.sref_model_set.argtypes = [C.c_void_p, C.c_int, _dp]
         L.sref_model_set_rot_const.argtypes = [C.c_void_p, C.c_double]
         L.sref_model_freq_scale.restype = C.c_double
         L.sref_model_freq_scale.argtypes = [C.c_void_p]
@@ -144,6 +145,11 @@ class Model:
         out = np.empty(len(self))
         lib().sref_model_get(self._h, self.FIELDS.index(name), _p(out))
         return out
+
+    def set_field(self, name, values):
+        v = _f64(values)
+        assert v.size == len(self)
+        lib().sref_model_set(self._h, self.FIELDS.index(name), _p(v))
 
     def set_rotation_constant(self, value):
         lib().sref_model_set_rot_const(self._h, value)

@@ -69,6 +69,15 @@ void sref_model_set_rot_const(void* m, double value) {
   DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
   std::fill(d.rot.begin(), d.rot.end(), value);
 }
+// Overwrite one model field (same indices as sref_model_get), e.g. a non-uniform rotation profile
+// (what set-rotation-overlay does, src/model/gsm.rs:116-127, after unit conversion).
+int sref_model_set(void* m, int field, const double* in) {
+  DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
+  if (field < 0 || field > 6) return -1;
+  std::copy(in, in + f[field]->size(), f[field]->begin());
+  return 0;
+}
 double sref_model_freq_scale(void* m) {  // DimensionedProperties::freq_scale, model.rs:127-129
   const DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
   if (!d.has_scale) return 0.;

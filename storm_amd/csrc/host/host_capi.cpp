@@ -1,0 +1,158 @@
+// host_capi.cpp -- flat C view of storm_host.hpp for the ctypes tests and bench.py
+// (libstorm_host.so).  Not part of the drop-in boundary (that is include/storm_hip.h); it only
+// lets Python drive the C++ host mirror of the reference's Rust interface.
+#include <cstring>
+#include <string>
+
+#include "storm_host.hpp"
+
+using namespace storm_host;
+
+namespace {
+thread_local std::string g_err;
+
+struct HostModel {
+  DiscreteModel discrete;
+  bool is_poly0 = false;
+  double gamma1 = 0.;
+  std::unique_ptr<ContinuousModel> continuous() const {
+    if (is_poly0) return std::make_unique<Polytrope0>(gamma1);
+    return std::make_unique<LinearInterpolator>(discrete);
+  }
+};
+
+template <class F>
+int guarded(F&& f) {
+  try { f(); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+  catch (...) { g_err = "unknown error"; return -1; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* storm_host_last_error() { return g_err.c_str(); }
+
+void* storm_host_model_from_gsm(size_t n, const double* r, const double* m_r, const double* rho, const double* p,
+                                const double* gamma1, const double* n2, const double* omega_rot, double r_star,
+                                double m_star) {
+  HostModel* h = new HostModel();
+  if (guarded([&] { h->discrete = DiscreteModel::from_gsm_arrays(n, r, m_r, rho, p, gamma1, n2, omega_rot, r_star, m_star); })) {
+    delete h; return nullptr;
+  }
+  return h;
+}
+void* storm_host_model_polytrope(double n, double gamma1, double step) {
+  HostModel* h = new HostModel();
+  if (guarded([&] { h->discrete = construct_polytrope(n, gamma1, step); })) { delete h; return nullptr; }
+  return h;
+}
+void* storm_host_model_poly0(double gamma1) {
+  HostModel* h = new HostModel();
+  h->is_poly0 = true; h->gamma1 = gamma1;
+  return h;
+}
+void storm_host_model_free(void* m) { delete static_cast<HostModel*>(m); }
+size_t storm_host_model_len(void* m) { return static_cast<HostModel*>(m)->discrete.len(); }
+// field: 0 r_coord, 1 v, 2 u, 3 gamma1, 4 a_star, 5 c1, 6 rot
+int storm_host_model_get(void* m, int field, double* out) {
+  DimensionlessProperties& d = static_cast<HostModel*>(m)->discrete.dimensionless;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
+  if (field < 0 || field > 6) return -1;
+  std::memcpy(out, f[field]->data(), f[field]->size() * sizeof(double));
+  return 0;
+}
+int storm_host_model_set(void* m, int field, const double* in) {
+  DimensionlessProperties& d = static_cast<HostModel*>(m)->discrete.dimensionless;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
+  if (field < 0 || field > 6) return -1;
+  std::memcpy(f[field]->data(), in, f[field]->size() * sizeof(double));
+  return 0;
+}
+// set-rotation-constant with dynamical units (src/main.rs:770-791)
+int storm_host_model_set_rotation_constant(void* m, double value) {
+  HostModel* h = static_cast<HostModel*>(m);
+  if (h->is_poly0) { g_err = "Setting the rotation profile for analytical polytropes is not supported"; return -1; }
+  for (double& r : h->discrete.dimensionless.rot) r = value;
+  return 0;
+}
+size_t storm_host_model_grid(void* m, size_t scale, double* out, size_t cap) {
+  HostModel* h = static_cast<HostModel*>(m);
+  std::vector<double> g = h->is_poly0 ? grid_of(*h->continuous(), scale) : grid_of(h->discrete, scale);
+  if (out) std::memcpy(out, g.data(), std::min(cap, g.size()) * sizeof(double));
+  return g.size();
+}
+
+void* storm_host_solver_new(void* m, uint64_t ell, int64_t mm, int scheme, const double* grid, size_t ngrid) {
+  HostModel* h = static_cast<HostModel*>(m);
+  ErasedSolver* s = nullptr;
+  if (guarded([&] {
+        if (scheme < 0 || scheme > 7) throw std::runtime_error("unknown difference scheme");
+        auto cm = h->continuous();
+        s = new ErasedSolver(*cm, Rotating1D::make(ell, mm), DifferenceSchemes(scheme),
+                             std::vector<double>(grid, grid + ngrid));
+      })) return nullptr;
+  return s;
+}
+void storm_host_solver_free(void* s) { delete static_cast<ErasedSolver*>(s); }
+size_t storm_host_solver_len(void* s) { return static_cast<ErasedSolver*>(s)->len(); }
+void* storm_host_solver_handle(void* s) { return static_cast<ErasedSolver*>(s)->handle(); }
+
+int storm_host_solver_det(void* s, const double* f, size_t n, double* out) {
+  return guarded([&] {
+    std::vector<double> r = static_cast<ErasedSolver*>(s)->det(std::vector<double>(f, f + n));
+    std::memcpy(out, r.data(), n * sizeof(double));
+  });
+}
+// precision_kind: 0 = Precision::ULP(precision_ulp), 1 = Precision::Relative(precision_rel)
+int storm_host_solver_scan_and_optimize(void* s, const double* f, size_t n, int precision_kind, uint64_t precision_ulp,
+                                        double precision_rel, storm_bracket* out, size_t cap, size_t* n_out,
+                                        int* had_invalid) {
+  return guarded([&] {
+    bool inv = false;
+    const Precision prec = precision_kind == 0 ? Precision::ULP(precision_ulp) : Precision::Relative(precision_rel);
+    std::vector<BracketResult> r =
+        static_cast<ErasedSolver*>(s)->scan_and_optimize(std::vector<double>(f, f + n), prec, &inv);
+    *n_out = r.size();
+    if (had_invalid) *had_invalid = inv ? 1 : 0;
+    for (size_t k = 0; k < r.size() && k < cap; ++k)
+      out[k] = storm_bracket{r[k].lower.x, r[k].lower.f, r[k].upper.x, r[k].upper.f, r[k].root, r[k].evals};
+  });
+}
+int storm_host_solver_eigenvectors(void* s, const double* f, size_t n, double* out) {
+  return guarded([&] {
+    std::vector<double> r = static_cast<ErasedSolver*>(s)->eigenvectors(std::vector<double>(f, f + n));
+    std::memcpy(out, r.data(), r.size() * sizeof(double));
+  });
+}
+
+// StormState::scan: returns the number of modes; brackets [cap], eigenvectors [cap][(len+1)*4] (may be NULL).
+int storm_host_scan(void* m, const double* grid, size_t ngrid, uint64_t ell, int64_t mm, double lower, double upper,
+                    size_t steps, int inverse, double precision, int scheme, storm_bracket* out, double* vec_out,
+                    size_t cap, size_t* n_out) {
+  HostModel* h = static_cast<HostModel*>(m);
+  return guarded([&] {
+    auto cm = h->continuous();
+    std::vector<Solution> sol = scan(*cm, std::vector<double>(grid, grid + ngrid), ell, mm, lower, upper, steps,
+                                     inverse != 0, precision, DifferenceSchemes(scheme));
+    *n_out = sol.size();
+    for (size_t k = 0; k < sol.size() && k < cap; ++k) {
+      const BracketResult& b = sol[k].bracket;
+      out[k] = storm_bracket{b.lower.x, b.lower.f, b.upper.x, b.upper.f, b.root, b.evals};
+      if (vec_out) std::memcpy(vec_out + k * sol[k].eigenvector.size(), sol[k].eigenvector.data(),
+                               sol[k].eigenvector.size() * sizeof(double));
+    }
+  });
+}
+
+double storm_host_polytrope0_exact(double gamma1, uint64_t ell, int64_t radial_order) {
+  return Polytrope0(gamma1).exact(ell, radial_order);
+}
+void storm_host_linspace(double lo, double hi, size_t n, double* out) {
+  std::vector<double> g = linspace(lo, hi, n); std::memcpy(out, g.data(), n * sizeof(double));
+}
+void storm_host_rev_linspace(double lo, double hi, size_t n, double* out) {
+  std::vector<double> g = rev_linspace(lo, hi, n); std::memcpy(out, g.data(), n * sizeof(double));
+}
+
+}  // extern "C"

@@ -1,0 +1,335 @@
+// storm_host.cpp -- see storm_host.hpp.  Built with -ffp-contract=off.
+#include "storm_host.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace storm_host {
+
+namespace {
+constexpr double kGrav = 6.67430e-8;  // "as defined by MESA", gsm.rs:13
+constexpr double kPi = 3.14159265358979323846264338327950288;
+inline double pow3(double x) { return (x * x) * x; }  // f64::powi(3)
+
+void resize_all(DimensionlessProperties& d, size_t n) {
+  d.r_coord.assign(n, 0.); d.v.assign(n, 0.); d.u.assign(n, 0.); d.gamma1.assign(n, 0.);
+  d.a_star.assign(n, 0.); d.c1.assign(n, 0.); d.rot.assign(n, 0.);
+}
+
+[[noreturn]] void raise_abi(const char* what, int rc) {
+  throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + storm_last_error());
+}
+}  // namespace
+
+double DimensionedProperties::freq_scale() const { return std::sqrt(grav * mass / pow3(radius)); }
+
+DiscreteModel DiscreteModel::from_gsm_arrays(size_t n, const double* r, const double* m_r, const double* rho,
+                                             const double* p, const double* gamma1, const double* n2,
+                                             const double* omega_rot, double r_star, double m_star) {
+  if (n < 2) throw std::runtime_error("GSM model needs at least 2 points");
+  DiscreteModel out;
+  out.scale = DimensionedProperties{r_star, m_star, kGrav};
+  DimensionlessProperties& d = out.dimensionless;
+  resize_all(d, n);
+  const double rs3 = pow3(r_star);
+  const double omega_dyn = std::sqrt(kGrav * m_star / rs3);
+  const double four_pi = 4. * kPi;
+  for (size_t k = 0; k < n; ++k) {
+    const double r3 = pow3(r[k]);
+    d.rot[k] = omega_rot[k] / omega_dyn;
+    d.c1[k] = r3 / rs3 * m_star / m_r[k];
+    d.a_star[k] = r3 / (kGrav * m_r[k]) * n2[k];
+    d.v[k] = kGrav * m_r[k] * rho[k] / (p[k] * r[k]);
+    d.u[k] = four_pi * rho[k] * r3 / m_r[k];
+    d.r_coord[k] = r[k] / r_star;
+    d.gamma1[k] = gamma1[k];
+  }
+  // the centre is a removable singularity: analytic limits, gsm.rs:84-90
+  d.c1[0] = m_star / rs3 * 3. / (four_pi * rho[0]);
+  d.a_star[0] = 0.;
+  d.v[0] = 0.;
+  d.u[0] = 3.;
+  return out;
+}
+
+DiscreteModel LinearInterpolator::eval(const std::vector<double>& grid) const {
+  const DimensionlessProperties& src = model_.dimensionless;
+  DiscreteModel out;
+  out.scale = model_.scale;
+  DimensionlessProperties& dst = out.dimensionless;
+  resize_all(dst, grid.size());
+  if (grid.empty()) throw std::runtime_error("LinearInterpolator::eval: empty grid");
+  const std::vector<double>& x = src.r_coord;
+  // Two cursors, one over the model grid and one over the requested points (both ascending),
+  // advanced exactly like the reference loop (interpolate.rs:50-117).
+  size_t feed = 0, lo = 0, hi = 0, q = 0;
+  while (true) {
+    const double want = grid[q];
+    if (x[hi] == want) {
+      dst.r_coord[q] = x[hi]; dst.v[q] = src.v[hi]; dst.u[q] = src.u[hi]; dst.gamma1[q] = src.gamma1[hi];
+      dst.a_star[q] = src.a_star[hi]; dst.c1[q] = src.c1[hi]; dst.rot[q] = src.rot[hi];
+      if (++q == grid.size()) break;
+      continue;
+    }
+    if (x[hi] > want) {
+      const double pos = (want - x[lo]) / (x[hi] - x[lo]);
+      auto lerp = [&](const std::vector<double>& f) { return f[lo] + pos * (f[hi] - f[lo]); };
+      dst.r_coord[q] = want;
+      dst.v[q] = lerp(src.v); dst.u[q] = lerp(src.u); dst.gamma1[q] = lerp(src.gamma1);
+      dst.a_star[q] = lerp(src.a_star); dst.c1[q] = lerp(src.c1); dst.rot[q] = lerp(src.rot);
+      if (++q == grid.size()) break;
+      continue;
+    }
+    lo = hi;
+    if (feed == x.size()) break;  // requested points beyond the model stay zero, like the reference
+    hi = feed++;
+  }
+  return out;
+}
+
+namespace {
+constexpr double kPoly0MaxX =
+    2.449489742783178098197284074705891391965947480656670128432692567250960377457315;  // sqrt(6)
+}
+
+double Polytrope0::exact(uint64_t ell, int64_t radial_order) const {  // Pekeris 1938, polytrope.rs:178-186
+  const double n = double(ell), k = 2. * double(radial_order);
+  const double d = -2. + gamma1 / 4. * (k * (k + 5. + 2. * n) + 6. + 4. * n);
+  return std::sqrt(d + std::sqrt(d * d + n * (n + 1.)));
+}
+
+DiscreteModel Polytrope0::eval(const std::vector<double>& grid) const {
+  DiscreteModel out;
+  DimensionlessProperties& d = out.dimensionless;
+  resize_all(d, grid.size());
+  for (size_t k = 0; k < grid.size(); ++k) {
+    const double xi = grid[k] * kPoly0MaxX;
+    const double theta = 1. - xi * xi / 6.;
+    const double phi = pow3(xi) / 3.;
+    d.r_coord[k] = grid[k];
+    d.v[k] = phi / (xi * theta);
+    d.a_star[k] = -phi / (xi * theta * gamma1);
+    d.u[k] = 3.; d.gamma1[k] = gamma1; d.c1[k] = 1.; d.rot[k] = 0.;
+  }
+  if (!grid.empty()) { d.v[0] = 0.; d.a_star[0] = 0.; }  // polytrope.rs:210,219 (index 0 of the *evaluated* grid)
+  return out;
+}
+
+std::vector<double> linspace(double lower, double upper, size_t n) {
+  std::vector<double> out(n);
+  for (size_t k = 0; k < n; ++k) out[k] = lower + (upper - lower) * double(k) / double(n - 1);
+  return out;
+}
+std::vector<double> rev_linspace(double lower, double upper, size_t n) {
+  std::vector<double> out = linspace(1. / lower, 1. / upper, n);
+  for (double& x : out) x = 1. / x;
+  return out;
+}
+std::vector<double> grid_of(const DiscreteModel& model, size_t scale) {
+  const std::vector<double>& r = model.dimensionless.r_coord;
+  std::vector<double> g;
+  g.reserve((r.size() - 1) * scale + 1);
+  for (size_t k = 0; k + 1 < r.size(); ++k)
+    for (size_t s = 0; s < scale; ++s) g.push_back(r[k] + (r[k + 1] - r[k]) * double(s) / double(scale));
+  g.push_back(r.back());
+  return g;
+}
+std::vector<double> grid_of(const ContinuousModel& model, size_t npoints) {
+  return linspace(model.inner(), model.outer(), npoints);
+}
+
+// ---- Lane-Emden integration for construct_polytrope (polytrope.rs:9-84) ----
+namespace {
+struct Deriv { double dphi, dtheta; };
+Deriv lane_emden_rhs(double xi, double phi, double theta, double n) {
+  const double dphi = std::pow(theta, n) * (xi * xi);
+  return Deriv{dphi, xi == 0. ? 0. : -phi / (xi * xi)};
+}
+struct State { double phi, theta; };
+State rk4_step(double xi, State s, double n, double h) {
+  const double hh = h / 2.;
+  const Deriv k1 = lane_emden_rhs(xi, s.phi, s.theta, n);
+  const Deriv k2 = lane_emden_rhs(xi + hh, s.phi + hh * k1.dphi, s.theta + hh * k1.dtheta, n);
+  const Deriv k3 = lane_emden_rhs(xi + hh, s.phi + hh * k2.dphi, s.theta + hh * k2.dtheta, n);
+  const Deriv k4 = lane_emden_rhs(xi + h, s.phi + h * k3.dphi, s.theta + h * k3.dtheta, n);
+  return State{s.phi + h / 6. * (k1.dphi + 2. * k2.dphi + 2. * k3.dphi + k4.dphi),
+               s.theta + h / 6. * (k1.dtheta + 2. * k2.dtheta + 2. * k3.dtheta + k4.dtheta)};
+}
+inline double sgn(double f) { return f != f ? f : (std::signbit(f) ? -1. : 1.); }
+inline uint64_t bits(double x) { uint64_t b; std::memcpy(&b, &x, 8); return b; }
+inline double unbits(uint64_t b) { double x; std::memcpy(&x, &b, 8); return x; }
+
+// InverseQuadratic::optimize (bracket.rs:151-222) for a scalar host function; used only to locate
+// the surface of the polytrope (polytrope.rs:49-69).  The scan's brackets are refined inside
+// libstorm_hip, not here.
+template <class F>
+BracketResult refine_host(Point lo, Point hi, F&& fn, uint64_t ulp) {
+  bool have_prev = false;
+  Point prev{0., 0.};
+  uint64_t evals = 0;
+  auto sec = [](Point a, Point b) { return (0. - b.f) / (a.f - b.f) * a.x + (0. - a.f) / (b.f - a.f) * b.x; };
+  while (true) {
+    double x;
+    if (!have_prev) {
+      x = sec(lo, hi);
+    } else {
+      const Point &a = lo, &b = hi, &c = prev;
+      x = (0. - b.f) * (0. - c.f) / (a.f - b.f) / (a.f - c.f) * a.x +
+          (0. - a.f) * (0. - c.f) / (b.f - a.f) / (b.f - c.f) * b.x +
+          (0. - a.f) * (0. - b.f) / (c.f - b.f) / (c.f - a.f) * c.x;
+      if (x <= lo.x || x >= hi.x) x = sec(lo, hi);
+    }
+    const uint64_t ub = bits(hi.x), lb = bits(lo.x);
+    if (!(hi.x > lo.x) || !(lo.x >= 0.)) throw std::runtime_error("refine_host: invalid bracket");
+    if (ub - lb <= ulp) return BracketResult{lo, hi, x, evals};
+    uint64_t xb = bits(x);
+    if (ub - lb <= 2 * ulp) xb = lb + (ub - lb) / 2;
+    else if (ub < xb || ub - xb < ulp) xb = ub - ulp;
+    else if (lb > xb || xb - lb < ulp) xb = lb + ulp;
+    x = unbits(xb);
+    const Point next{x, fn(x)};
+    if (!std::isfinite(next.f)) throw std::runtime_error("refine_host: non-finite value");
+    ++evals;
+    if (sgn(hi.f) == sgn(next.f)) { prev = hi; hi = next; } else { prev = lo; lo = next; }
+    have_prev = true;
+  }
+}
+}  // namespace
+
+DiscreteModel construct_polytrope(double n, double gamma1, double step) {
+  if (!(n < 5.) || !(n >= 0.)) throw std::runtime_error("polytropic index must be in [0, 5)");
+  std::vector<double> xi, theta, phi;
+  State s{0., 1.};
+  uint64_t count = 0;
+  while (s.theta > 0.) {
+    theta.push_back(s.theta); phi.push_back(s.phi); xi.push_back(double(count) * step);
+    s = rk4_step(double(count) * step, s, n, step);
+    ++count;
+  }
+  const double x_last = double(count - 1) * step;
+  const State last{phi.back(), theta.back()};
+  const BracketResult br = refine_host(Point{0., last.theta}, Point{step, s.theta},
+                                       [&](double h) { return rk4_step(x_last, last, n, h).theta; }, 1);
+  const State surf = rk4_step(x_last, last, n, br.lower.x);
+  const double max_phi = surf.phi, max_xi = x_last + br.root;
+  const size_t len = xi.size();  // the surface point itself is dropped (polytrope.rs:99-101)
+  DiscreteModel out;
+  DimensionlessProperties& d = out.dimensionless;
+  resize_all(d, len);
+  for (size_t k = 0; k < len; ++k) {
+    d.u[k] = pow3(xi[k]) * std::pow(theta[k], n) / phi[k];
+    d.v[k] = (n + 1.) * phi[k] / (xi[k] * theta[k]);
+    d.c1[k] = pow3(xi[k]) / pow3(max_xi) * max_phi / phi[k];
+    d.a_star[k] = -((n + 1.) / gamma1 - n) * phi[k] / (xi[k] * theta[k]);
+    d.r_coord[k] = xi[k] / max_xi;
+    d.gamma1[k] = gamma1;
+    d.rot[k] = 0.;
+  }
+  d.u[0] = 3.; d.v[0] = 0.; d.a_star[0] = 0.;
+  d.c1[0] = max_phi / pow3(max_xi) * 3.;
+  return out;
+}
+
+// ---- ErasedSolver ----
+namespace {
+void abscissae(DifferenceSchemes scheme, std::vector<double>& out) {  // Stepper::points(), stepper.rs
+  constexpr double c2 = 0.28867513459481287, c3 = 0.3872983346207417;
+  constexpr double c4a = 0.8611363115940526 / 2., c4b = 0.33998104358485626 / 2.;
+  switch (int(scheme) & 3) {
+    case 0: out = {0.5}; break;
+    case 1: out = {0.5 + -c2, 0.5 + c2}; break;
+    case 2: out = {0.5 + -c3, 0.5 + 0., 0.5 + c3}; break;
+    default: out = {0.5 + -c4a, 0.5 + -c4b, 0.5 + c4b, 0.5 + c4a}; break;
+  }
+}
+}  // namespace
+
+ErasedSolver::ErasedSolver(const ContinuousModel& model, Rotating1D system, DifferenceSchemes scheme,
+                           const std::vector<double>& grid) {
+  if (grid.empty()) throw std::runtime_error("ErasedSolver::new: empty solver grid");
+  std::vector<double> loc;
+  abscissae(scheme, loc);
+  const size_t p = loc.size(), steps = grid.size() - 1;
+  // DiscretizedSystemImpl::new, discretized.rs:94-100
+  std::vector<double> delta(steps), xs(steps * p);
+  for (size_t i = 0; i < steps; ++i) delta[i] = grid[i + 1] - grid[i];
+  for (size_t i = 0; i < steps; ++i)
+    for (size_t j = 0; j < p; ++j) xs[i * p + j] = grid[i] + loc[j] * delta[i];
+  std::vector<double> u, vg, as, c1, rot, dx(steps * p);
+  if (steps) {
+    const DiscreteModel at = model.eval(xs);
+    const DimensionlessProperties& d = at.dimensionless;
+    u = d.u; as = d.a_star; c1 = d.c1; rot = d.rot;
+    vg.resize(steps * p);
+    for (size_t k = 0; k < steps * p; ++k) vg[k] = d.v[k] / d.gamma1[k];  // adiabatic.rs:52
+    for (size_t i = 0; i < steps; ++i)
+      for (size_t j = 0; j < p; ++j) dx[i * p + j] = delta[i] / xs[i * p + j];
+  }
+  const DiscreteModel in = model.eval({model.inner()}), outm = model.eval({model.outer()});  // discretized.rs:119-120
+  storm_system_desc desc{};
+  desc.scheme = int32_t(scheme);
+  desc.ell = system.ell; desc.m = system.m;
+  desc.n_int = steps; desc.p = p;
+  desc.u = u.data(); desc.v_gamma = vg.data(); desc.a_star = as.data(); desc.c1 = c1.data();
+  desc.rot = rot.data(); desc.delta_over_x = dx.data();
+  desc.inner_c1 = in.dimensionless.c1[0];
+  desc.inner_rot = in.dimensionless.rot[0];
+  desc.outer_u = outm.dimensionless.u[0];
+  const int rc = storm_solver_create(&desc, &h_);
+  if (rc != STORM_OK) raise_abi("storm_solver_create", rc);
+  n_int_ = steps;
+}
+
+ErasedSolver::~ErasedSolver() { storm_solver_destroy(h_); }
+
+double ErasedSolver::det(double freq) const {
+  double out = 0.;
+  const int rc = storm_det_batch(h_, &freq, 1, &out);
+  if (rc != STORM_OK) raise_abi("storm_det_batch", rc);
+  return out;
+}
+std::vector<double> ErasedSolver::det(const std::vector<double>& freqs) const {
+  std::vector<double> out(freqs.size());
+  const int rc = storm_det_batch(h_, freqs.data(), freqs.size(), out.data());
+  if (rc != STORM_OK) raise_abi("storm_det_batch", rc);
+  return out;
+}
+std::vector<double> ErasedSolver::eigenvector(double freq) const { return eigenvectors({freq}); }
+std::vector<double> ErasedSolver::eigenvectors(const std::vector<double>& freqs) const {
+  std::vector<double> out(freqs.size() * (n_int_ + 1) * 4);
+  const int rc = storm_eigenvector_batch(h_, freqs.data(), freqs.size(), nullptr, out.data());
+  if (rc != STORM_OK) raise_abi("storm_eigenvector_batch", rc);
+  return out;
+}
+std::vector<BracketResult> ErasedSolver::scan_and_optimize(const std::vector<double>& grid, Precision precision,
+                                                           bool* had_invalid) const {
+  std::vector<storm_bracket> raw(grid.size() ? grid.size() : 1);
+  size_t n_out = 0;
+  int invalid = 0;
+  const int rc = storm_scan_and_optimize(h_, grid.data(), grid.size(), precision.as_ulp(), raw.data(), raw.size(),
+                                         &n_out, &invalid, nullptr, nullptr);
+  if (rc != STORM_OK) raise_abi("storm_scan_and_optimize", rc);
+  if (had_invalid) *had_invalid = invalid != 0;
+  std::vector<BracketResult> out(n_out);
+  for (size_t k = 0; k < n_out; ++k)
+    out[k] = BracketResult{Point{raw[k].lo_x, raw[k].lo_f}, Point{raw[k].hi_x, raw[k].hi_f}, raw[k].root, raw[k].evals};
+  return out;
+}
+
+std::vector<Solution> scan(const ContinuousModel& model, const std::vector<double>& solver_grid, uint64_t ell,
+                           int64_t m, double lower, double upper, size_t steps, bool inverse, double precision,
+                           DifferenceSchemes scheme) {
+  ErasedSolver determinant(model, Rotating1D::make(ell, m), scheme, solver_grid);
+  const std::vector<double> points = inverse ? rev_linspace(lower, upper, steps) : linspace(lower, upper, steps);
+  const std::vector<BracketResult> res = determinant.scan_and_optimize(points, Precision::Relative(precision));
+  std::vector<double> roots(res.size());
+  for (size_t k = 0; k < res.size(); ++k) roots[k] = res[k].root;
+  const std::vector<double> vecs = determinant.eigenvectors(roots);
+  const size_t len = (determinant.len() + 1) * 4;
+  std::vector<Solution> out(res.size());
+  for (size_t k = 0; k < res.size(); ++k)
+    out[k] = Solution{res[k], std::vector<double>(vecs.begin() + k * len, vecs.begin() + (k + 1) * len), ell, m};
+  return out;
+}
+
+}  // namespace storm_host

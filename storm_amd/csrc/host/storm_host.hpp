@@ -1,0 +1,152 @@
+// storm_host.hpp -- C++ host side above the C ABI, mirroring the reference's Rust interface for
+// the scan path name for name, so a StORM user finds the same calls:
+//
+//   reference (Rust)                                   here (C++)
+//   DiscreteModel::from_gsm           model/gsm.rs:68   DiscreteModel::from_gsm_arrays (HDF5 stays with the caller)
+//   construct_polytrope               polytrope.rs:90   construct_polytrope
+//   Polytrope0                        polytrope.rs:168  Polytrope0
+//   LinearInterpolator                interpolate.rs:6  LinearInterpolator
+//   ContinuousModel                   model.rs:17       ContinuousModel
+//   Rotating1D::new                   adiabatic.rs:19   Rotating1D
+//   DifferenceSchemes                 dynamic_interface.rs:24
+//   Precision                         bracket.rs:19     Precision
+//   ErasedSolver::{new,det,eigenvector,scan_and_optimize}   dynamic_interface.rs:60-160
+//   Model::grid, linspace, rev_linspace, StormState::scan   main.rs:661-679,793-838,1232-1238
+//
+// The Rust host does exactly this work before it reaches the FFI seam: interpolate
+// the model at the collocation abscissae (DiscretizedSystemImpl::new, discretized.rs:81-123) and
+// hand the coefficient arrays to storm_solver_create.  Everything numeric below keeps the
+// reference's operation order (built with -ffp-contract=off) so inputs to the GPU are bit-identical.
+// Errors: where the reference panics, these throw std::runtime_error.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/storm_hip.h"
+
+namespace storm_host {
+
+struct DimensionedProperties {  // model.rs:93-102
+  double radius, mass, grav;
+  double freq_scale() const;    // model.rs:127-129
+};
+
+struct DimensionlessProperties {  // model.rs:70-91 (fields the scan path consumes)
+  std::vector<double> r_coord, v, u, gamma1, a_star, c1, rot;
+};
+
+struct DiscreteModel {  // model.rs:6-13
+  DimensionlessProperties dimensionless;
+  std::optional<DimensionedProperties> scale;
+  // The numeric part of from_gsm (gsm.rs:81-103) on datasets the caller has read from the GSM file.
+  static DiscreteModel from_gsm_arrays(size_t n, const double* r, const double* m_r, const double* rho,
+                                       const double* p, const double* gamma1, const double* n2,
+                                       const double* omega_rot, double r_star, double m_star);
+  size_t len() const { return dimensionless.r_coord.size(); }
+};
+
+DiscreteModel construct_polytrope(double n, double gamma1, double step);  // polytrope.rs:90-165
+
+class ContinuousModel {  // model.rs:17-26
+ public:
+  virtual ~ContinuousModel() = default;
+  virtual double inner() const = 0;
+  virtual double outer() const = 0;
+  virtual DiscreteModel eval(const std::vector<double>& grid) const = 0;
+  virtual std::optional<DimensionedProperties> dimensions() const = 0;
+};
+
+class LinearInterpolator : public ContinuousModel {  // interpolate.rs
+ public:
+  explicit LinearInterpolator(const DiscreteModel& model) : model_(model) {}
+  double inner() const override { return model_.dimensionless.r_coord.front(); }
+  double outer() const override { return model_.dimensionless.r_coord.back(); }
+  DiscreteModel eval(const std::vector<double>& grid) const override;
+  std::optional<DimensionedProperties> dimensions() const override { return model_.scale; }
+ private:
+  const DiscreteModel& model_;
+};
+
+class Polytrope0 : public ContinuousModel {  // polytrope.rs:168-248
+ public:
+  explicit Polytrope0(double gamma1) : gamma1(gamma1) {}
+  double gamma1;
+  double exact(uint64_t ell, int64_t radial_order) const;
+  double inner() const override { return 0.; }
+  double outer() const override { return 1.; }
+  DiscreteModel eval(const std::vector<double>& grid) const override;
+  std::optional<DimensionedProperties> dimensions() const override { return std::nullopt; }
+};
+
+struct Rotating1D {  // adiabatic.rs:12-25
+  uint64_t ell;
+  int64_t m;
+  static Rotating1D make(uint64_t ell, int64_t m) { return Rotating1D{ell, m}; }
+};
+
+enum class DifferenceSchemes : int {  // dynamic_interface.rs:24-57
+  Colloc2 = 0, Colloc4, Colloc6, Colloc8, Magnus2, Magnus4, Magnus6, Magnus8
+};
+
+struct Precision {  // bracket.rs:19-40
+  bool relative;
+  uint64_t ulp;
+  double rel;
+  static Precision ULP(uint64_t u) {
+    if (u == 0) throw std::runtime_error("Precision::ULP needs a non-zero value");
+    return Precision{false, u, 0.};
+  }
+  static Precision Relative(double f) { return Precision{true, 0, f}; }
+  uint64_t as_ulp() const { return relative ? storm_precision_relative_to_ulp(rel) : ulp; }
+};
+
+struct Point { double x, f; };                                             // bracket.rs:63-68
+struct BracketResult { Point lower, upper; double root; uint64_t evals; };  // bracket.rs:6-15
+
+std::vector<double> linspace(double lower, double upper, size_t n);      // main.rs:1232-1234
+std::vector<double> rev_linspace(double lower, double upper, size_t n);  // main.rs:1236-1238
+// Model::grid (main.rs:661-679): every interval of the model grid split `scale` times.
+std::vector<double> grid_of(const DiscreteModel& model, size_t scale);
+std::vector<double> grid_of(const ContinuousModel& model, size_t npoints);
+
+class ErasedSolver {  // dynamic_interface.rs:60-160
+ public:
+  ErasedSolver(const ContinuousModel& model, Rotating1D system, DifferenceSchemes scheme,
+               const std::vector<double>& solver_grid);
+  ~ErasedSolver();
+  ErasedSolver(const ErasedSolver&) = delete;
+  ErasedSolver& operator=(const ErasedSolver&) = delete;
+
+  double det(double freq) const;
+  std::vector<double> det(const std::vector<double>& freqs) const;  // batched convenience
+  std::vector<double> eigenvector(double freq) const;
+  // Batched form of the per-mode loop of StormState::scan (main.rs:824-831); row-major [n][(n_int+1)*4].
+  std::vector<double> eigenvectors(const std::vector<double>& freqs) const;
+  std::vector<BracketResult> scan_and_optimize(const std::vector<double>& freq_grid, Precision precision,
+                                               bool* had_invalid_numbers = nullptr) const;
+  size_t len() const { return n_int_; }
+  storm_solver* handle() const { return h_; }
+
+ private:
+  storm_solver* h_ = nullptr;
+  size_t n_int_ = 0;
+};
+
+struct Solution {  // main.rs:1225-1230
+  BracketResult bracket;
+  std::vector<double> eigenvector;
+  uint64_t ell;
+  int64_t m;
+};
+
+// StormState::scan (main.rs:793-838) with frequencies in dynamical units.
+std::vector<Solution> scan(const ContinuousModel& model, const std::vector<double>& solver_grid, uint64_t ell,
+                           int64_t m, double lower, double upper, size_t steps, bool inverse, double precision,
+                           DifferenceSchemes scheme);
+
+}  // namespace storm_host

@@ -1,0 +1,253 @@
+"""ctypes binding of the C++ host mirror (storm_amd/csrc/host/storm_host.hpp -> libstorm_host.so).
+
+Names follow the reference's Rust API for the scan path (DiscreteModel, Polytrope0,
+construct_polytrope, ErasedSolver.{det,eigenvector,scan_and_optimize}, Precision, scan) so the
+parity tests read like the reference's own tests (src/dynamic_interface.rs:223-522)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ffi
+from .ffi import Bracket, SCHEMES
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def host_lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstorm_host.so")
+
+
+def load_host_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    ffi.load_library()  # fail loudly if the HIP library is missing
+    path = host_lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `make -C storm_amd/csrc`")
+    L = C.CDLL(path)
+    L.storm_host_last_error.restype = C.c_char_p
+    L.storm_host_model_from_gsm.restype = C.c_void_p
+    L.storm_host_model_from_gsm.argtypes = [C.c_size_t] + [_dp] * 7 + [C.c_double] * 2
+    L.storm_host_model_polytrope.restype = C.c_void_p
+    L.storm_host_model_polytrope.argtypes = [C.c_double] * 3
+    L.storm_host_model_poly0.restype = C.c_void_p
+    L.storm_host_model_poly0.argtypes = [C.c_double]
+    L.storm_host_model_free.argtypes = [C.c_void_p]
+    L.storm_host_model_len.restype = C.c_size_t
+    L.storm_host_model_len.argtypes = [C.c_void_p]
+    L.storm_host_model_get.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.storm_host_model_set.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.storm_host_model_set_rotation_constant.argtypes = [C.c_void_p, C.c_double]
+    L.storm_host_model_grid.restype = C.c_size_t
+    L.storm_host_model_grid.argtypes = [C.c_void_p, C.c_size_t, _dp, C.c_size_t]
+    L.storm_host_solver_new.restype = C.c_void_p
+    L.storm_host_solver_new.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, _dp, C.c_size_t]
+    L.storm_host_solver_free.argtypes = [C.c_void_p]
+    L.storm_host_solver_len.restype = C.c_size_t
+    L.storm_host_solver_len.argtypes = [C.c_void_p]
+    L.storm_host_solver_handle.restype = C.c_void_p
+    L.storm_host_solver_handle.argtypes = [C.c_void_p]
+    L.storm_host_solver_det.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp]
+    L.storm_host_solver_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, C.c_uint64, C.c_double,
+                                                      C.POINTER(Bracket), C.c_size_t, C.POINTER(C.c_size_t),
+                                                      C.POINTER(C.c_int)]
+    L.storm_host_solver_eigenvectors.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp]
+    L.storm_host_scan.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_uint64, C.c_int64, C.c_double, C.c_double,
+                                  C.c_size_t, C.c_int, C.c_double, C.c_int, C.POINTER(Bracket), _dp, C.c_size_t,
+                                  C.POINTER(C.c_size_t)]
+    L.storm_host_polytrope0_exact.restype = C.c_double
+    L.storm_host_polytrope0_exact.argtypes = [C.c_double, C.c_uint64, C.c_int64]
+    L.storm_host_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
+    L.storm_host_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
+    _lib = L
+    return L
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _err():
+    return HostError(load_host_library().storm_host_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def linspace(lo, hi, n):
+    out = np.empty(n)
+    load_host_library().storm_host_linspace(lo, hi, n, _p(out))
+    return out
+
+
+def rev_linspace(lo, hi, n):
+    out = np.empty(n)
+    load_host_library().storm_host_rev_linspace(lo, hi, n, _p(out))
+    return out
+
+
+class Precision:
+    def __init__(self, kind, ulp=1, rel=0.0):
+        self.kind, self.ulp, self.rel = kind, ulp, rel
+
+    @classmethod
+    def ULP(cls, u):
+        return cls(0, ulp=int(u))
+
+    @classmethod
+    def Relative(cls, f):
+        return cls(1, rel=float(f))
+
+
+class Model:
+    """DiscreteModel / ContinuousModel handle on the C++ host side."""
+    FIELDS = ["r_coord", "v", "u", "gamma1", "a_star", "c1", "rot"]
+
+    def __init__(self, handle, poly0=False):
+        if not handle:
+            raise _err()
+        self._h = C.c_void_p(handle)
+        self.poly0 = poly0
+
+    @classmethod
+    def from_gsm_npz(cls, path):
+        d = np.load(path)
+        arrs = [_f64(d[k]) for k in ("r", "M_r", "rho", "P", "Gamma_1", "N2", "Omega_rot")]
+        return cls(load_host_library().storm_host_model_from_gsm(int(d["n"]), *[_p(a) for a in arrs],
+                                                                 float(d["R_star"]), float(d["M_star"])))
+
+    @classmethod
+    def construct_polytrope(cls, n, gamma1, step):
+        return cls(load_host_library().storm_host_model_polytrope(n, gamma1, step))
+
+    @classmethod
+    def Polytrope0(cls, gamma1):
+        return cls(load_host_library().storm_host_model_poly0(gamma1), poly0=True)
+
+    def __len__(self):
+        return load_host_library().storm_host_model_len(self._h)
+
+    def field(self, name):
+        out = np.empty(len(self))
+        load_host_library().storm_host_model_get(self._h, self.FIELDS.index(name), _p(out))
+        return out
+
+    def set_field(self, name, values):
+        v = _f64(values)
+        assert v.size == len(self)
+        load_host_library().storm_host_model_set(self._h, self.FIELDS.index(name), _p(v))
+
+    def set_rotation_constant(self, value):
+        if load_host_library().storm_host_model_set_rotation_constant(self._h, value) != 0:
+            raise _err()
+
+    def grid(self, scale=1):
+        L = load_host_library()
+        n = L.storm_host_model_grid(self._h, scale, None, 0)
+        out = np.empty(n)
+        L.storm_host_model_grid(self._h, scale, _p(out), n)
+        return out
+
+    def __del__(self):
+        try:
+            load_host_library().storm_host_model_free(self._h)
+        except Exception:
+            pass
+
+
+class ErasedSolver:
+    """ErasedSolver::new(model, Rotating1D::new(ell, m), scheme, solver_grid) on the MI355X."""
+
+    def __init__(self, model, ell, m, scheme, solver_grid):
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        g = _f64(solver_grid)
+        h = load_host_library().storm_host_solver_new(model._h, ell, m, scheme, _p(g), g.size)
+        if not h:
+            raise _err()
+        self._h = C.c_void_p(h)
+        self._model = model
+        self.n_int = load_host_library().storm_host_solver_len(self._h)
+        self.scheme, self.ell, self.m = scheme, ell, m
+
+    def raw_handle(self):
+        return load_host_library().storm_host_solver_handle(self._h)
+
+    def set_option(self, key, value):
+        L = ffi.load_library()
+        rc = L.storm_solver_set_option(C.c_void_p(self.raw_handle()), key.encode(), int(value))
+        if rc != 0:
+            raise ffi.StormError(rc, L.storm_last_error().decode())
+
+    def stats(self, reset=False):
+        L = ffi.load_library()
+        s = ffi.Stats()
+        rc = L.storm_solver_stats(C.c_void_p(self.raw_handle()), C.byref(s), 1 if reset else 0)
+        if rc != 0:
+            raise ffi.StormError(rc, L.storm_last_error().decode())
+        return {k: int(getattr(s, k)) for k, _ in ffi.Stats._fields_}
+
+    def det(self, freqs):
+        f = _f64(np.atleast_1d(freqs))
+        out = np.empty(f.size)
+        if load_host_library().storm_host_solver_det(self._h, _p(f), f.size, _p(out)) != 0:
+            raise _err()
+        return out
+
+    def scan_and_optimize(self, freq_grid, precision):
+        f = _f64(freq_grid)
+        cap = max(1, f.size)
+        out = (Bracket * cap)()
+        n_out, inv = C.c_size_t(0), C.c_int(0)
+        rc = load_host_library().storm_host_solver_scan_and_optimize(self._h, _p(f), f.size, precision.kind,
+                                                                     precision.ulp, precision.rel, out, cap,
+                                                                     C.byref(n_out), C.byref(inv))
+        if rc != 0:
+            raise _err()
+        res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals))
+               for b in out[:n_out.value]]
+        return res, bool(inv.value)
+
+    def eigenvector(self, freqs):
+        f = _f64(np.atleast_1d(freqs))
+        out = np.empty((f.size, (self.n_int + 1) * 4))
+        if load_host_library().storm_host_solver_eigenvectors(self._h, _p(f), f.size, _p(out)) != 0:
+            raise _err()
+        return out
+
+    def __del__(self):
+        try:
+            load_host_library().storm_host_solver_free(self._h)
+        except Exception:
+            pass
+
+
+def scan(model, solver_grid, ell, m, lower, upper, steps, inverse=False, precision=1e-8, scheme="colloc4"):
+    """StormState::scan (reference src/main.rs:793-838), dynamical frequency units."""
+    if isinstance(scheme, str):
+        scheme = SCHEMES.index(scheme)
+    g = _f64(solver_grid)
+    cap = max(1, steps)
+    out = (Bracket * cap)()
+    vec = np.empty((cap, g.size * 4))
+    n_out = C.c_size_t(0)
+    rc = load_host_library().storm_host_scan(model._h, _p(g), g.size, ell, m, lower, upper, steps, 1 if inverse else 0,
+                                             precision, scheme, out, _p(vec), cap, C.byref(n_out))
+    if rc != 0:
+        raise _err()
+    n = n_out.value
+    res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals))
+           for b in out[:n]]
+    return res, vec[:n].copy()
+
+
+def polytrope0_exact(gamma1, ell, radial_order):
+    return load_host_library().storm_host_polytrope0_exact(gamma1, ell, radial_order)

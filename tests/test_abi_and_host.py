@@ -1,0 +1,92 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/storm_hip.h
+declares, argument validation works without a GPU, and the C++ host mirror's model layer
+agrees bit-for-bit with the oracle's.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "storm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(storm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from storm_amd import ffi
+    L = ffi.load_library()
+    declared = _declared_functions()
+    assert declared, "no declarations parsed"
+    assert sorted(ffi.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(L, name), f"libstorm_hip.so does not export {name}"
+    assert b"gfx950" in L.storm_version()
+
+
+def test_argument_validation_without_gpu():
+    from storm_amd import ffi
+    L = ffi.load_library()
+    h = C.c_void_p()
+    assert L.storm_solver_create(None, C.byref(h)) == -1
+    d = ffi.SystemDesc()
+    d.scheme = 99
+    assert L.storm_solver_create(C.byref(d), C.byref(h)) == -1
+    assert b"scheme" in L.storm_last_error()
+    d.scheme = 1
+    d.p = 3  # colloc4 has 2 points
+    assert L.storm_solver_create(C.byref(d), C.byref(h)) == -1
+    L.storm_solver_destroy(None)  # must be a no-op
+    assert L.storm_det_batch(None, None, 0, None) == -1
+
+
+def test_no_cpu_fallback_when_no_gpu():
+    """Without a HIP device creation must fail with STORM_ERR_HIP, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from storm_amd import ffi
+    L = ffi.load_library()
+    one = np.ones(1)
+    p = one.ctypes.data_as(C.POINTER(C.c_double))
+    d = ffi.SystemDesc(0, 0, 0, 1, 1, p, p, p, p, p, p, 1.0, 0.0, 3.0)
+    h = C.c_void_p()
+    assert L.storm_solver_create(C.byref(d), C.byref(h)) == -2
+    assert not h.value
+
+
+def test_precision_conversion():
+    from storm_amd import ffi
+    assert ffi.relative_to_ulp(1e-8) == 45035996   # CLI default, reference src/bracket.rs:30-40
+    assert ffi.relative_to_ulp(0.0) == 1
+    assert ffi.relative_to_ulp(1e-300) == 1
+
+
+@pytest.mark.parametrize("name", ["zams", "tams"])
+def test_host_model_matches_oracle(oracle, oracle_models, golden_dir, name):
+    from storm_amd import host
+    hm = host.Model.from_gsm_npz(os.path.join(golden_dir, f"gsm_{name}.npz"))
+    om = oracle_models(name)
+    for f in host.Model.FIELDS:
+        a, b = hm.field(f), om.field(f)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f
+    for scale in (1, 3):
+        assert np.array_equal(hm.grid(scale), om.grid(scale))
+
+
+def test_host_polytrope_matches_oracle(oracle):
+    from storm_amd import host
+    hm = host.Model.construct_polytrope(3.0, 5.0 / 3.0, 0.01)
+    om = oracle.Model.polytrope(3.0, 5.0 / 3.0, 0.01)
+    assert len(hm) == len(om) and len(hm) > 600
+    for f in host.Model.FIELDS:
+        assert np.array_equal(hm.field(f).view(np.uint64), om.field(f).view(np.uint64)), f
+    assert host.polytrope0_exact(5.0 / 3.0, 0, 1) == oracle.polytrope0_exact(5.0 / 3.0, 0, 1)
+    assert np.array_equal(host.linspace(1.0, 25.0, 1000), oracle.linspace(1.0, 25.0, 1000))
+    assert np.array_equal(host.rev_linspace(0.5, 1.0, 1000), oracle.rev_linspace(0.5, 1.0, 1000))
+    p0 = host.Model.Polytrope0(5.0 / 3.0)
+    assert np.array_equal(p0.grid(100), oracle.Model.poly0(5.0 / 3.0).grid(100))
