@@ -109,9 +109,17 @@ typedef struct {
 } storm_stats;
 int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
 
+/* Per-kernel device time, measured with HIP events recorded on the launch stream around every
+ * launch while option "profile" is 1.  ms_out / launches_out have STORM_KERNEL_KINDS entries. */
+enum { STORM_KERNEL_DET_FUSED = 0, STORM_KERNEL_BUILD_STEPS = 1, STORM_KERNEL_CHAIN = 2, STORM_KERNEL_EIGEN = 3,
+       STORM_KERNEL_KINDS = 4 };
+int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* launches_out, int reset);
+
 /* Tuning knobs; no effect on results (every path is bit-identical).
  *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels
- *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB) */
+ *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)
+ *   "fused_min_n": batch size from which "path" 0 picks the fused kernel
+ *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 
 size_t storm_solver_n_int(const storm_solver* solver);

@@ -73,6 +73,13 @@ struct storm_solver {
   size_t steps_bytes_max = size_t(4) << 30;
   size_t fused_min_n = 32768;                    // auto: fused kernel from this batch size on
   storm_stats stats{};
+  // optional per-kernel timing with HIP events on the launch stream (option "profile")
+  bool profile = false;
+  struct Timed { int kind; hipEvent_t start, stop; };
+  std::vector<Timed> pending;
+  std::vector<hipEvent_t> event_pool;
+  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0};
+  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0};
   std::mutex mu;
 };
 
@@ -146,10 +153,46 @@ void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& un
 
 void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
 
+hipEvent_t take_event(storm_solver* s) {
+  if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  hip_check(hipEventCreate(&e), "hipEventCreate");
+  return e;
+}
+// Brackets one launch with events on the stream it is launched on.
+struct ScopedTimer {
+  storm_solver* s; hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(storm_solver* s, hipStream_t st, int kind) : s(s), st(st), kind(kind) {
+    if (!s->profile) return;
+    a = take_event(s); b = take_event(s);
+    hip_check(hipEventRecord(a, st), "hipEventRecord");
+  }
+  void stop() {
+    if (!a) return;
+    hip_check(hipEventRecord(b, st), "hipEventRecord");
+    s->pending.push_back({kind, a, b});
+    a = nullptr;
+  }
+};
+// Call after the stream has been synchronised.
+void resolve_timers(storm_solver* s) {
+  for (auto& t : s->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      s->kernel_ms[t.kind] += ms;
+      s->kernel_launches[t.kind] += 1;
+    }
+    s->event_pool.push_back(t.start);
+    s->event_pool.push_back(t.stop);
+  }
+  s->pending.clear();
+}
+
 void check_flags(storm_solver* s) {
   int flags = 0;
   hip_check(hipMemcpyAsync(&flags, s->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, s->stream), "flags D2H");
   hip_check(hipStreamSynchronize(s->stream), "sync");
+  resolve_timers(s);
   if (flags & 1) {
     hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags reset");
     fail(STORM_ERR_SINGULAR, "singular collocation stage matrix (the reference would panic in try_inverse().unwrap())");
@@ -169,7 +212,9 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
   const size_t n_int = s->sys.n_int;
   const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
   if (fused) {
+    ScopedTimer t(s, st, STORM_KERNEL_DET_FUSED);
     hip_check(g_launch_fused[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
+    t.stop();
     count_launch(s);
   } else {
     const size_t per_freq = n_int * 16 * sizeof(double);
@@ -180,8 +225,12 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     s->d_steps.reserve(chunk * n_int * 16);
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
+      ScopedTimer tb(s, st, STORM_KERNEL_BUILD_STEPS);
       hip_check(g_launch_build[s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st)), "build_steps launch");
+      tb.stop();
+      ScopedTimer tc(s, st, STORM_KERNEL_CHAIN);
       hip_check(launch_chain(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
+      tc.stop();
       count_launch(s, 2);
     }
   }
@@ -350,6 +399,8 @@ void storm_solver_destroy(storm_solver* s) {
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(s->device);
   if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+  for (auto& t : s->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
   s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
   s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release();
   (void)hipSetDevice(prev);
@@ -369,6 +420,8 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     } else if (k == "steps_bytes_max") {
       if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
       s->steps_bytes_max = size_t(value);
+    } else if (k == "profile") {
+      s->profile = value != 0;
     } else if (k == "fused_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "fused_min_n must be >= 0");
       s->fused_min_n = size_t(value);
@@ -384,6 +437,15 @@ int storm_solver_stats(storm_solver* s, storm_stats* out, int reset) {
     std::lock_guard<std::mutex> lock(s->mu);
     *out = s->stats;
     if (reset) s->stats = storm_stats{};
+  });
+}
+
+int storm_solver_kernel_times(storm_solver* s, double* ms_out, uint64_t* launches_out, int reset) {
+  return guarded([&] {
+    if (!s || !ms_out || !launches_out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    for (int k = 0; k < STORM_KERNEL_KINDS; ++k) { ms_out[k] = s->kernel_ms[k]; launches_out[k] = s->kernel_launches[k]; }
+    if (reset) for (int k = 0; k < STORM_KERNEL_KINDS; ++k) { s->kernel_ms[k] = 0; s->kernel_launches[k] = 0; }
   });
 }
 
@@ -472,9 +534,13 @@ int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, doubl
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
       hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
+      ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
       hip_check(g_launch_build[s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
+      tb.stop();
+      ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
       hip_check(launch_eigen(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p, s->d_swaps.p, s->d_det.p,
                              s->d_vec.p, s->stream), "eigen launch");
+      te.stop();
       count_launch(s, 3);
       hip_check(hipMemcpyAsync(vec_out + off * len, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
       if (det_out)

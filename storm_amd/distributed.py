@@ -1,0 +1,73 @@
+"""Frequency-slice sharding of a scan over the GPUs of one node (one process per GPU).
+
+The reference runs one rayon task per scan frequency (src/dynamic_interface.rs:125-127); the two
+`collect()` barriers there are the only global points.  Here every rank evaluates a contiguous
+slice of the frequency grid plus ONE halo point on the right, so every adjacent pair (i, i+1) is
+owned by exactly the rank that owns i; brackets are refined where they are found and the
+(tiny, latency-bound) bracket lists are gathered with one all_gather of counts and one of padded
+records -- RCCL over xGMI on GPUs (`backend="nccl"`), gloo in the CPU tests.  There is no
+collective inside the data path.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD = 7  # lo_x, lo_f, hi_x, hi_f, root, evals, global index
+
+
+def shard_bounds(n, world, rank):
+    """Owned index range [lo, hi) of rank `rank`; the slice to evaluate is [lo, min(hi + 1, n))."""
+    per = -(-n // world) if n else 0
+    lo = min(n, rank * per)
+    hi = min(n, lo + per)
+    return lo, hi
+
+
+def local_slice(freqs, world, rank):
+    lo, hi = shard_bounds(len(freqs), world, rank)
+    return lo, freqs[lo:min(hi + 1, len(freqs))]
+
+
+def pack(brackets, offset):
+    rec = np.zeros((len(brackets), RECORD), dtype=np.float64)
+    for k, b in enumerate(brackets):
+        rec[k] = (b["lo_x"], b["lo_f"], b["hi_x"], b["hi_f"], b["root"], float(b["evals"]), float(b["index"] + offset))
+    return rec
+
+
+def unpack(rec):
+    return [dict(lo_x=r[0], lo_f=r[1], hi_x=r[2], hi_f=r[3], root=r[4], evals=int(r[5]), index=int(r[6]))
+            for r in rec]
+
+
+def gather_brackets(local_records, invalid, device):
+    """all_gather of per-rank bracket records -> (global records in ascending order, any_invalid)."""
+    world = dist.get_world_size()
+    count = torch.tensor([local_records.shape[0], 1 if invalid else 0], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = torch.stack(counts).cpu().numpy()
+    cap = max(1, int(counts[:, 0].max()))
+    buf = torch.zeros((cap, RECORD), dtype=torch.float64, device=device)
+    if local_records.shape[0]:
+        buf[:local_records.shape[0]] = torch.from_numpy(local_records).to(device)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    parts = [bufs[r][:int(counts[r, 0])].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, RECORD)), bool(counts[:, 1].any())
+
+
+def sharded_scan_and_optimize(solver, freqs, ulp, device="cpu"):
+    """scan_and_optimize of the whole grid, sharded over the ranks of the default process group.
+
+    `solver` needs .scan_and_optimize(freqs, ulp) -> (brackets with 'index', dets, invalid).
+    Returns (all brackets in ascending order, any_invalid, this rank's local brackets)."""
+    freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        res, _, inv = solver.scan_and_optimize(freqs, ulp)
+        return res, inv, res
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, mine = local_slice(freqs, world, rank)
+    res, _, inv = solver.scan_and_optimize(mine, ulp) if len(mine) else ([], None, False)
+    rec, any_inv = gather_brackets(pack(res, lo), inv, device)
+    return unpack(rec), any_inv, res

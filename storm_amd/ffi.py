@@ -39,7 +39,7 @@ class Stats(C.Structure):
 # every symbol include/storm_hip.h declares
 EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "storm_det_batch_device",
            "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
-           "storm_solver_stats", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
+           "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
            "storm_version"]
 
 _lib = None
@@ -68,11 +68,23 @@ def load_library():
     L.storm_precision_relative_to_ulp.restype = C.c_uint64
     L.storm_precision_relative_to_ulp.argtypes = [C.c_double]
     L.storm_solver_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L.storm_solver_kernel_times.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_uint64), C.c_int]
     L.storm_solver_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.storm_solver_n_int.restype = C.c_size_t
     L.storm_solver_n_int.argtypes = [C.c_void_p]
     _lib = L
     return L
+
+
+KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen"]
+
+
+def kernel_times(handle, reset=False):
+    """{kind: (total_ms, launches)} from HIP events (option "profile" must be on)."""
+    ms = (C.c_double * 4)()
+    cnt = (C.c_uint64 * 4)()
+    _check(load_library().storm_solver_kernel_times(C.c_void_p(handle), ms, cnt, 1 if reset else 0))
+    return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
 
 
 def _check(rc):
@@ -130,6 +142,9 @@ class HipSolver:
         s = Stats()
         _check(load_library().storm_solver_stats(self._h, C.byref(s), 1 if reset else 0))
         return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def kernel_times(self, reset=False):
+        return kernel_times(self._h.value, reset)
 
     def det(self, freqs):
         f = _f64(np.atleast_1d(freqs))

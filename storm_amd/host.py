@@ -195,6 +195,9 @@ class ErasedSolver:
             raise ffi.StormError(rc, L.storm_last_error().decode())
         return {k: int(getattr(s, k)) for k, _ in ffi.Stats._fields_}
 
+    def kernel_times(self, reset=False):
+        return ffi.kernel_times(self.raw_handle(), reset)
+
     def det(self, freqs):
         f = _f64(np.atleast_1d(freqs))
         out = np.empty(f.size)
