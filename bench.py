@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- scan throughput of the HIP path on BASELINE.json's config 2.
+
+A "step" is one pass of the hot path over the whole batch: for tams (6199 intervals),
+ell = 1,2,3 x {Magnus6, Colloc8}: scan_and_optimize over linspace(1, 25, 10^4) at relative
+precision 1e-8, then the eigenvector of every mode found (= StormState::scan, reference
+src/main.rs:793-838, six times).  Model coefficients are resident in HBM before the timed
+region (solvers are created outside it).  value = (frequency x interval) discriminant
+evaluations per second over the whole job (scan + refinement evaluations, eigenvector time
+included in the denominator), summed over all ranks.
+
+N > 1 (weak scaling): the grid becomes linspace(1, 25, N*10^4); every rank evaluates a contiguous
+slice (+1 halo point), brackets are gathered with RCCL (storm_amd/distributed.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic flops per (frequency, interval) evaluation, reference form (add/sub/mul/div = 1,
+# un-fused), frozen by the oracle's op-counting scalar (tests/test_oracle_golden.py,
+# oracle/storm_ref.hpp Counted) for ell != 0 with uniform rotation.  See DESIGN.md.
+FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "colloc8": 5048.1,
+                  "magnus2": 1486.0, "magnus4": 1848.0, "magnus6": 2562.0, "magnus8": 3900.1}
+PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz); = dense FP64 MFMA peak
+
+CASES = [(ell, scheme) for scheme in ("magnus6", "colloc8") for ell in (1, 2, 3)]
+N_FREQ_PER_GPU = 10000
+PRECISION = 1e-8
+
+
+def cpu_baseline(npz, budget_s=15.0):
+    """The CPU oracle (a port of the reference algorithm, -O2 -ffp-contract=off) on a bounded sample
+    of the same workload: the first `k` frequencies of each of the six scans, all host cores."""
+    from oracle import storm_ref
+    storm_ref.build()
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64)
+    model = storm_ref.Model.from_gsm_npz(npz)
+    grid = model.field("r_coord")
+    freqs = storm_ref.linspace(1.0, 25.0, N_FREQ_PER_GPU)
+    solvers = [storm_ref.Solver(model, ell, 0, scheme, grid) for ell, scheme in CASES]
+    # calibrate on a small sample, then size the timed sample to ~budget_s
+    t0 = time.perf_counter()
+    for s in solvers:
+        s.det(freqs[:cores], threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    k = int(max(cores, min(N_FREQ_PER_GPU, cores * budget_s / dt)))
+    k -= k % cores
+    sample = freqs[np.linspace(0, N_FREQ_PER_GPU - 1, k).astype(int)]
+    t0 = time.perf_counter()
+    for s in solvers:
+        s.det(sample, threads=cores)
+    dt = time.perf_counter() - t0
+    evals = len(solvers) * k * solvers[0].n_int
+    return {"value": evals / dt, "unit": "freq*interval evals/s", "cores": cores, "kind": "port",
+            "sample": f"{k} of {N_FREQ_PER_GPU} scan frequencies (evenly spaced) of each of the 6 scans "
+                      f"(tams, ell=1..3 x magnus6/colloc8), discriminant only, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads", type=int, default=6, help="host threads driving independent scans (1 = sequential)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from storm_amd import host, distributed as D
+    npz = os.path.join(ROOT, "tests", "golden", "gsm_tams.npz")
+    model = host.Model.from_gsm_npz(npz)
+    grid = model.field("r_coord")
+    n_total = N_FREQ_PER_GPU * world
+    freqs = host.linspace(1.0, 25.0, n_total)
+    ulp = __import__("storm_amd").relative_to_ulp(PRECISION)
+
+    solvers = []
+    for ell, scheme in CASES:
+        s = host.ErasedSolver(model, ell, 0, scheme, grid)
+        s.set_option("profile", 1)
+        solvers.append(s)
+    n_int = solvers[0].n_int
+
+    class RawScan:
+        """adapter: C-ABI scan on the raw handle with bracket indices (for the sharded gather)"""
+        def __init__(self, es):
+            import ctypes as C
+            from storm_amd import ffi
+            self.h, self.C, self.ffi = C.c_void_p(es.raw_handle()), C, ffi
+
+        def scan_and_optimize(self, f, ulp):
+            C, ffi = self.C, self.ffi
+            f = np.ascontiguousarray(f, dtype=np.float64)
+            cap = max(1, f.size)
+            out = (ffi.Bracket * cap)()
+            idx = (C.c_uint64 * cap)()
+            n_out, inv = C.c_size_t(0), C.c_int(0)
+            rc = ffi.load_library().storm_scan_and_optimize(self.h, f.ctypes.data_as(C.POINTER(C.c_double)), f.size,
+                                                            ulp, out, cap, C.byref(n_out), C.byref(inv), None, idx)
+            if rc != 0:
+                raise ffi.StormError(rc, ffi.load_library().storm_last_error().decode())
+            res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
+                        index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
+            return res, None, bool(inv.value)
+
+    raws = [RawScan(s) for s in solvers]
+
+    # The six scans are independent jobs on independent handles (each with its own HIP stream):
+    # run them from six host threads so the latency-bound phases of one scan (bracket refinement
+    # rounds, eigenvector elimination) overlap the throughput-bound step-matrix kernels of the others.
+    # ctypes releases the GIL inside the library.  Collectives (N > 1) stay on the main thread.
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=len(solvers)) if args.threads > 1 else None
+
+    def scan_one(k):
+        torch.cuda.set_device(local_rank)
+        lo, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
+        res, _, inv = raws[k].scan_and_optimize(mine, ulp) if len(mine) else ([], None, False)
+        if res:
+            solvers[k].eigenvector(np.array([b["root"] for b in res]))
+        return lo, res, inv
+
+    def one_step():
+        if pool is not None:
+            parts = list(pool.map(scan_one, range(len(solvers))))
+        else:
+            parts = [scan_one(k) for k in range(len(solvers))]
+        modes_global = 0
+        for lo, res, inv in parts:
+            if world > 1:
+                rec, _ = D.gather_brackets(D.pack(res, lo), inv, device)
+                modes_global += rec.shape[0]
+            else:
+                modes_global += len(res)
+        return modes_global
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    for s in solvers:
+        s.stats(reset=True)
+        s.kernel_times(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    modes = 0
+    for _ in range(args.steps):
+        modes = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    det_evals = sum(s.stats()["det_evals"] for s in solvers)
+    refine = sum(s.stats()["refine_evals"] for s in solvers)
+    eigs = sum(s.stats()["eigenvectors"] for s in solvers)
+    if world > 1:
+        t = torch.tensor([det_evals, refine, eigs], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        det_evals, refine, eigs = (int(x) for x in t.tolist())
+
+    # Per-kernel device time inside the timed region (HIP events on each solver's launch stream).
+    # With six scans in flight these durations overlap each other, so they are reported as they
+    # are but NOT used for the roofline.
+    per_kind = {}
+    for (ell, scheme), s in zip(CASES, solvers):
+        for kind, (ms, cnt) in s.kernel_times().items():
+            if cnt:
+                d = per_kind.setdefault((kind, scheme), {"ms": 0.0, "launches": 0})
+                d["ms"] += ms
+                d["launches"] += cnt
+    kernel_summary = {f"{k}/{sch}": {"ms_total": round(v["ms"], 3), "launches": v["launches"],
+                                      "avg_ms": round(v["ms"] / v["launches"], 4)} for (k, sch), v in per_kind.items()}
+    dom_kind, dom_scheme = max(per_kind.items(), key=lambda kv: kv[1]["ms"])[0]
+
+    # Roofline of the dominant kernel: the same launch (same solver, same 10^4-frequency slice, same
+    # grid) repeated alone on the device, timed with HIP events on the stream it is launched on.
+    roofline = None
+    if rank == 0:
+        k_dom = max((k for k, (ell, sch) in enumerate(CASES) if sch == dom_scheme), key=lambda k: CASES[k][0])
+        sd = solvers[k_dom]
+        lo, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
+        sd.det(mine)
+        sd.kernel_times(reset=True)
+        reps = 5
+        for _ in range(reps):
+            sd.det(mine)
+        kt = {k: v for k, v in sd.kernel_times(reset=True).items() if v[1]}
+        kind = max(kt.items(), key=lambda kv: kv[1][0])[0]
+        ms, cnt = kt[kind]
+        flops_per_rep = len(mine) * n_int * FLOPS_PER_EVAL[dom_scheme]
+        if kind == "build_steps":  # the ordered product (112 flop/eval) runs in the chain kernel
+            flops_per_rep = len(mine) * n_int * (FLOPS_PER_EVAL[dom_scheme] - 112.0)
+        achieved = flops_per_rep * reps / (ms * 1e-3) / 1e12
+        roofline = {"bound": "fp64-valu", "kernel": f"{kind}<{dom_scheme}>", "achieved": round(achieved, 3),
+                    "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt,
+                    "flops_per_launch": flops_per_rep * reps / cnt,
+                    "unfused_issue_ceiling_TFLOPs": 38.1,
+                    "note": "algorithmic un-fused flops (oracle op count x evals per launch) / HIP-event duration of the "
+                            "kernel run alone; arithmetic is the reference's separate mul and add (bit-exact parity), "
+                            "whose measured chip-wide issue ceiling is 38.1 TFLOP/s (tools/fp64_microbench.hip) = 0.485 "
+                            "of the FMA-counted peak; traffic: coefficient planes are L2-resident (see DESIGN.md)"}
+
+    if rank == 0:
+        value = det_evals * n_int / elapsed
+        out = {
+            "metric": "scan throughput: freq x gridpoint evals/sec (whole job: scan + bracket refinement + eigenvectors)",
+            "value": value, "unit": "freq*interval evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: test-model-tams (6199 intervals), ell=1..3, m=0, Magnus6 + "
+                                   "Colloc8, linspace(1,25,10^4 per GPU), precision 1e-8, + eigenvector per mode",
+                       "n_freq_total": n_total, "n_int": n_int, "scans": len(CASES),
+                       "parallelism": f"freq-slice x{world}", "concurrent_scans": args.threads if args.threads > 1 else 1},
+            "modes_per_s": modes * args.steps / elapsed if False else (eigs / elapsed),
+            "modes_per_step": modes, "det_evals": det_evals, "refine_evals": refine,
+            "kernels": kernel_summary, "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(npz, args.cpu_budget)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

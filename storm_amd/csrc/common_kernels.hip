@@ -22,7 +22,28 @@ SDEV double quad_bcast(double x) {
   return __hiloint2double(hi, lo);
 }
 
-constexpr int kChainUnroll = 4;
+constexpr int kChainBlock = 16;  // steps per register block; one block is prefetched while one is consumed
+
+struct RowBlock {
+  double2 lo[kChainBlock], hi[kChainBlock];
+};
+
+SDEV void chain_load(RowBlock& b, const double2* __restrict__ rows, size_t i0) {
+#pragma unroll
+  for (int u = 0; u < kChainBlock; ++u) {
+    b.lo[u] = rows[(i0 + u) * 8];
+    b.hi[u] = rows[(i0 + u) * 8 + 1];
+  }
+}
+
+SDEV double chain_step(double acc, double2 lo, double2 hi) {
+  const double a0 = quad_bcast<0>(acc), a1 = quad_bcast<1>(acc), a2 = quad_bcast<2>(acc), a3 = quad_bcast<3>(acc);
+  double t = lo.x * a0;
+  t = lo.y * a1 + t;
+  t = hi.x * a2 + t;
+  t = hi.y * a3 + t;
+  return t;
+}
 
 template <bool ELL0>
 __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
@@ -37,33 +58,20 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
   const double2* __restrict__ rows = reinterpret_cast<const double2*>(steps + fi * s.n_int * 16) + r * 2;
   double acc = (r == c) ? 1.0 : 0.0;
   const size_t n_int = s.n_int;
+  const size_t n_blocks = n_int / kChainBlock;
   size_t i = 0;
-  for (; i + kChainUnroll <= n_int; i += kChainUnroll) {
-    double2 lo[kChainUnroll], hi[kChainUnroll];
+  if (n_blocks > 0) {
+    RowBlock cur, nxt;
+    chain_load(nxt, rows, 0);
+    for (size_t b = 0; b < n_blocks; ++b) {
+      cur = nxt;
+      if (b + 1 < n_blocks) chain_load(nxt, rows, (b + 1) * kChainBlock);
 #pragma unroll
-    for (int u = 0; u < kChainUnroll; ++u) {
-      lo[u] = rows[(i + u) * 8];
-      hi[u] = rows[(i + u) * 8 + 1];
+      for (int u = 0; u < kChainBlock; ++u) acc = chain_step(acc, cur.lo[u], cur.hi[u]);
     }
-#pragma unroll
-    for (int u = 0; u < kChainUnroll; ++u) {
-      const double a0 = quad_bcast<0>(acc), a1 = quad_bcast<1>(acc), a2 = quad_bcast<2>(acc), a3 = quad_bcast<3>(acc);
-      double t = lo[u].x * a0;
-      t = lo[u].y * a1 + t;
-      t = hi[u].x * a2 + t;
-      t = hi[u].y * a3 + t;
-      acc = t;
-    }
+    i = n_blocks * kChainBlock;
   }
-  for (; i < n_int; ++i) {
-    const double2 lo = rows[i * 8], hi = rows[i * 8 + 1];
-    const double a0 = quad_bcast<0>(acc), a1 = quad_bcast<1>(acc), a2 = quad_bcast<2>(acc), a3 = quad_bcast<3>(acc);
-    double t = lo.x * a0;
-    t = lo.y * a1 + t;
-    t = hi.x * a2 + t;
-    t = hi.y * a3 + t;
-    acc = t;
-  }
+  for (; i < n_int; ++i) acc = chain_step(acc, rows[i * 8], rows[i * 8 + 1]);
   sh[tid] = acc;  // element (r, c) at group*16 + c*4 + r: column-major, as M4 wants it
   __syncthreads();
   if (sub == 0 && fi_raw < n) {
@@ -84,143 +92,158 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
 }
 
 // ---------------------------------------------------------------------------------------
-// Eigenvector: forward elimination.
+// Eigenvector: forward elimination, 8 lanes per mode.
+// Lane j of a group owns system column j of the 6x8 band (6 values).  For pivot K the owner's
+// column is broadcast to the group and every lane redoes the (tiny) pivot search, so all lanes
+// agree on the row swap and the multipliers without further traffic; each lane then updates its
+// own column.  Arithmetic per entry is exactly the reference's (row_pivot!/column_pivot!/sweep!,
+// src/solver.rs:163-269): m = B[r][K] * (1/pivot); B[r][j] -= prow[j] * m.
 // ---------------------------------------------------------------------------------------
-// One pivot of the 6x8 band (or of the closing 4x4).  COLPIV selects the column-pivot variant
-// used for the first two pivots of the first interval (reference column_pivot!, solver.rs:192-230).
-// `up` receives prow[i]*pinv for i = K+1..COLS-1 (reference sweep! first arm, solver.rs:164-174).
-template <int ROWS, int COLS, int K, bool COLPIV>
-SDEV void pivot_sweep_upper(double (&B)[6][8], double& det, double* __restrict__ up, int* swap_out) {
-  double prow[COLS];
-  if constexpr (COLPIV) {
-    int max_idx = K;
-    double max_val = __builtin_fabs(B[K][K]);
+SDEV double group_bcast(double x, int src) {  // value of lane `src` (0..7) of this 8-lane group
+  return __shfl(x, src, 8);
+}
+
+// ROWS x COLS elimination step K on column-distributed data.  `b` = this lane's column.
+// `up_base` points at the packed upper row of this pivot; lane j > K stores prow*pinv at [j-K-1].
+template <int ROWS, int COLS, int K>
+SDEV void group_pivot(double (&b)[6], int j, double& det, double* __restrict__ up_base, bool search_rows) {
+  double ck[6];
 #pragma unroll
-    for (int i = K + 1; i < COLS; ++i) {
-      const double v = __builtin_fabs(B[K][i]);
-      if (v > max_val) { max_idx = i; max_val = v; }
+  for (int r = K; r < ROWS; ++r) ck[r] = group_bcast(b[r], K);
+  int max_idx = K;
+  if (search_rows) {
+    double max_val = __builtin_fabs(ck[K]);
+#pragma unroll
+    for (int r = K + 1; r < ROWS; ++r) {
+      const double v = __builtin_fabs(ck[r]);
+      if (v > max_val) { max_idx = r; max_val = v; }
     }
-    // swap system columns max_idx and K in rows K..ROWS-1
-#pragma unroll
-    for (int i = K + 1; i < COLS; ++i) {
-      const bool sel = (i == max_idx);
-#pragma unroll
-      for (int rr = K; rr < ROWS; ++rr) {
-        const double a = B[rr][i], b = B[rr][K];
-        B[rr][i] = sel ? b : a;
-        B[rr][K] = sel ? a : b;
-      }
-    }
-    if (max_idx != K) det = det * -1.0;
-    *swap_out = max_idx;  // == K when no swap happened
-#pragma unroll
-    for (int j = 0; j < COLS; ++j) prow[j] = B[K][j];
-  } else {
-    int max_idx = K;
-    double max_val = __builtin_fabs(B[K][K]);
-#pragma unroll
-    for (int i = K + 1; i < ROWS; ++i) {
-      const double v = __builtin_fabs(B[i][K]);
-      if (v > max_val) { max_idx = i; max_val = v; }
-    }
-#pragma unroll
-    for (int j = 0; j < COLS; ++j) prow[j] = B[K][j];
-#pragma unroll
-    for (int i = K + 1; i < ROWS; ++i) {
-      const bool sel = (i == max_idx);
-#pragma unroll
-      for (int j = 0; j < COLS; ++j) {
-        const double old = B[i][j];
-        prow[j] = sel ? old : prow[j];
-        B[i][j] = sel ? B[K][j] : old;
-      }
-    }
-    if (max_idx != K) det = det * -1.0;
   }
-  const double pivot = prow[K];
+  double prow = b[K];
+  double pivot = ck[K];
+#pragma unroll
+  for (int r = K + 1; r < ROWS; ++r) {
+    const bool sel = (r == max_idx);
+    const double old = b[r], oldc = ck[r];
+    prow = sel ? old : prow;
+    pivot = sel ? oldc : pivot;
+    b[r] = sel ? b[K] : old;
+    ck[r] = sel ? ck[K] : oldc;
+  }
+  if (max_idx != K) det = det * -1.0;
   det = det * pivot;
   const double pinv = 1.0 / pivot;
+  if (j > K && j < COLS) up_base[j - K - 1] = prow * pinv;
 #pragma unroll
-  for (int i = K + 1; i < COLS; ++i) up[i - K - 1] = prow[i] * pinv;
-#pragma unroll
-  for (int rr = K + 1; rr < ROWS; ++rr) {
-    const double m = B[rr][K] * pinv;
-#pragma unroll
-    for (int j = 0; j < COLS; ++j) B[rr][j] = B[rr][j] - prow[j] * m;
+  for (int r = K + 1; r < ROWS; ++r) {
+    const double m = ck[r] * pinv;
+    b[r] = b[r] - prow * m;
   }
 }
 
-template <bool FIRST>
-SDEV void eliminate_interval(double (&B)[6][8], double& det, const double* __restrict__ lrow,
-                             double* __restrict__ up, int* swaps) {
-  // rows 2..5 <- [L | -I]; lrow is the row-major step matrix
+// column_pivot! (src/solver.rs:192-230) for pivot K of the first interval: pick the largest entry
+// of system row K among columns K..7, exchange the two columns in rows K..5.
+template <int K>
+SDEV int group_column_swap(double (&b)[6], int j, double& det) {
+  int max_idx = K;
+  double max_val = __builtin_fabs(group_bcast(b[K], K));
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int i = K + 1; i < 8; ++i) {
+    const double v = __builtin_fabs(group_bcast(b[K], i));
+    if (v > max_val) { max_idx = i; max_val = v; }
+  }
+  const int src = (j == K) ? max_idx : ((j == max_idx) ? K : j);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      B[r + 2][c] = lrow[r * 4 + c];
-      B[r + 2][c + 4] = (r == c) ? -1.0 : 0.0;
-    }
-  int dummy;
-  pivot_sweep_upper<6, 8, 0, FIRST>(B, det, up + 0, FIRST ? &swaps[0] : &dummy);
-  pivot_sweep_upper<6, 8, 1, FIRST>(B, det, up + 7, FIRST ? &swaps[1] : &dummy);
-  pivot_sweep_upper<6, 8, 2, false>(B, det, up + 13, &dummy);
-  pivot_sweep_upper<6, 8, 3, false>(B, det, up + 18, &dummy);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { B[i][j] = B[i + 4][j + 4]; B[i][j + 4] = 0.0; }
+  for (int r = K; r < 6; ++r) b[r] = group_bcast(b[r], src);
+  if (max_idx != K) det = det * -1.0;
+  return max_idx;
 }
+
+constexpr int kEigBlock = 8;  // intervals per prefetched register block
 
 template <bool ELL0>
 __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                            const double* __restrict__ steps,
                                                            double* __restrict__ upper, int* __restrict__ swaps,
                                                            double* __restrict__ det_out) {
-  const size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (m >= n) return;
+  const int tid = threadIdx.x;
+  const int j = tid & 7;
+  const size_t m_raw = (size_t)blockIdx.x * 8 + (tid >> 3);
+  const size_t m = m_raw < n ? m_raw : n - 1;  // surplus groups shadow the last mode (their stores are identical)
   const double f = freq[m];
   const size_t n_int = s.n_int;
   const size_t ustride = n_int * 22 + 6;
   double* __restrict__ up = upper + m * ustride;
-  const double* __restrict__ st = steps + m * n_int * 16;
-  double B[6][8];
+  // lane j < 4 reads column j of the row-major step matrix: entries j, 4+j, 8+j, 12+j
+  const double* __restrict__ st = steps + m * n_int * 16 + (j & 3);
+  double b[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) B[r][c] = 0.0;
-  B[0][0] = inner_00<ELL0>(s, f);
-  B[0][1] = -s.ell; B[0][2] = -s.ell;
-  B[1][2] = s.ell;  B[1][3] = -1.0;
+  for (int r = 0; r < 6; ++r) b[r] = 0.0;
+  // inner boundary rows (reference src/system/adiabatic.rs:154-183)
+  {
+    const double i00 = inner_00<ELL0>(s, f);
+    b[0] = (j == 0) ? i00 : ((j == 1 || j == 2) ? -s.ell : 0.0);
+    b[1] = (j == 2) ? s.ell : ((j == 3) ? -1.0 : 0.0);
+  }
   double det = 1.0;
-  int sw[2] = {0, 1};
-  if (n_int > 0) {
-    double l[16];
+  int sw0 = 0, sw1 = 1;
+  double cur[kEigBlock][4], nxt[kEigBlock][4];
+  auto load_block = [&](double (&dst)[kEigBlock][4], size_t i0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) l[e] = st[e];
-    eliminate_interval<true>(B, det, l, up, sw);
-  }
-  for (size_t i = 1; i < n_int; ++i) {
-    double l[16];
+    for (int u = 0; u < kEigBlock; ++u) {
+      const size_t i = (i0 + u < n_int) ? i0 + u : n_int - 1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) l[e] = st[i * 16 + e];
-    eliminate_interval<false>(B, det, l, up + i * 22, sw);
+      for (int r = 0; r < 4; ++r) dst[u][r] = st[i * 16 + r * 4];
+    }
+  };
+  if (n_int > 0) load_block(nxt, 0);
+  for (size_t i0 = 0; i0 < n_int; i0 += kEigBlock) {
+#pragma unroll
+    for (int u = 0; u < kEigBlock; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cur[u][r] = nxt[u][r];
+    if (i0 + kEigBlock < n_int) load_block(nxt, i0 + kEigBlock);
+#pragma unroll
+    for (int u = 0; u < kEigBlock; ++u) {
+      const size_t i = i0 + u;
+      if (i < n_int) {
+        // rows 2..5 <- [L | -I]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r + 2] = (j < 4) ? cur[u][r] : ((j - 4 == r) ? -1.0 : 0.0);
+        double* __restrict__ upi = up + i * 22;
+        if (i == 0) {
+          sw0 = group_column_swap<0>(b, j, det);
+          group_pivot<6, 8, 0>(b, j, det, upi + 0, false);
+          sw1 = group_column_swap<1>(b, j, det);
+          group_pivot<6, 8, 1>(b, j, det, upi + 7, false);
+        } else {
+          group_pivot<6, 8, 0>(b, j, det, upi + 0, true);
+          group_pivot<6, 8, 1>(b, j, det, upi + 7, true);
+        }
+        group_pivot<6, 8, 2>(b, j, det, upi + 13, true);
+        group_pivot<6, 8, 3>(b, j, det, upi + 18, true);
+        // the two untouched rows move up: B[i][j] = B[i+4][j+4], right half cleared
+        const double t4 = __shfl_down(b[4], 4, 8), t5 = __shfl_down(b[5], 4, 8);
+        b[0] = (j < 4) ? t4 : 0.0;
+        b[1] = (j < 4) ? t5 : 0.0;
+      }
+    }
   }
-  swaps[m * 2 + 0] = sw[0];
-  swaps[m * 2 + 1] = sw[1];
-  // outer boundary rows and the closing 4x4
-  B[2][0] = 1.0; B[2][1] = -1.0; B[2][2] = 0.0; B[2][3] = 0.0;
-  B[3][0] = s.outer_u; B[3][1] = 0.0; B[3][2] = s.ell + 1.0; B[3][3] = 1.0;
+  if (j == 0 && m_raw < n) { swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1; }
+  // outer boundary rows (reference src/system/adiabatic.rs:185-208) and the closing 4x4
+  b[2] = (j == 0) ? 1.0 : ((j == 1) ? -1.0 : 0.0);
+  b[3] = (j == 0) ? s.outer_u : ((j == 2) ? s.ell + 1.0 : ((j == 3) ? 1.0 : 0.0));
   double* __restrict__ uf = up + n_int * 22;
-  int dummy;
-  pivot_sweep_upper<4, 4, 0, false>(B, det, uf + 0, &dummy);
-  pivot_sweep_upper<4, 4, 1, false>(B, det, uf + 3, &dummy);
-  pivot_sweep_upper<4, 4, 2, false>(B, det, uf + 5, &dummy);
-  det_out[m] = det * B[3][3];
+  group_pivot<4, 4, 0>(b, j, det, uf + 0, true);
+  group_pivot<4, 4, 1>(b, j, det, uf + 3, true);
+  group_pivot<4, 4, 2>(b, j, det, uf + 5, true);
+  const double last = group_bcast(b[3], 3);
+  if (j == 0 && m_raw < n) det_out[m] = det * last;
 }
 
 // Back-substitution.  `upper` is walked backwards exactly like the reference's reversed
-// iterator; e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.
+// iterator; e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.  One lane per
+// mode; the 22 factors of the next interval are prefetched while the current one is consumed.
 __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
                                                            const int* __restrict__ swaps, double* __restrict__ vec) {
   const size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -229,52 +252,46 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
   const size_t len = (n_int + 1) * 4;
   const double* __restrict__ d = upper + m * ustride;
   double* __restrict__ e = vec + m * len;
-  size_t it = ustride;  // reverse cursor
-  // w[0] is the most recently produced component, w[k] the one produced k steps earlier
-  double w[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) w[k] = 0.0;
-  w[0] = 1.0;
   e[len - 1] = 1.0;
-  // closing 4x4: components len-2, len-3, len-4
+  // closing 4x4 (reference src/solver.rs:107-113): packed rows {k=0: 3, k=1: 2, k=2: 1 entries}
+  const double* __restrict__ df = d + n_int * 22;
+  const double e3 = 1.0;
+  const double e2 = 0.0 - df[5] * e3;
+  const double e1 = (0.0 - df[4] * e3) - df[3] * e2;
+  const double e0 = ((0.0 - df[2] * e3) - df[1] * e2) - df[0] * e1;
+  e[len - 2] = e2; e[len - 3] = e1; e[len - 4] = e0;
+  // base[0..3] = components of the grid point to the right, last component first
+  double b0 = e3, b1 = e2, b2 = e1, b3 = e0;
+  double cur[22], nxt[22];
+  if (n_int > 0) {
 #pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    double nv = 0.0;
-#pragma unroll
-    for (int j = 0; j < i; ++j) nv = nv - d[--it] * w[i - 1 - j];
-    // e[len-j-1] for j = 0..i-1 are w[i-1], w[i-2], ..., w[0] (oldest first)
-#pragma unroll
-    for (int k = 6; k > 0; --k) w[k] = w[k - 1];
-    w[0] = nv;
-    e[len - i - 1] = nv;
+    for (int q = 0; q < 22; ++q) nxt[q] = d[(n_int - 1) * 22 + q];
   }
-  // now w[0..3] = e[len-4], e[len-3], e[len-2], e[len-1]
   for (size_t k = 0; k < n_int; ++k) {
-    // the 4 components of grid point (n_int - 1 - k); they depend on the last 4..7 produced
-    // reference: e[len - i - (k+1)*4 - 1] = -sum_{j < i+4} data.next() * e[len - j - k*4 - 1]
-    // e[len - j - k*4 - 1], j = 0..: the first component of the previous block is j = 3.
-    double base[7];
-    // base[j] = e[len - j - k*4 - 1]; before this block w holds the previous block newest-first:
-    // w[0] = e[len - 3 - k*4 - 1] ... w[3] = e[len - 0 - k*4 - 1]
-    base[0] = w[3]; base[1] = w[2]; base[2] = w[1]; base[3] = w[0];
-    double nv0 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) nv0 = nv0 - d[--it] * base[j];
-    base[4] = nv0;
-    double nv1 = 0.0;
+    for (int q = 0; q < 22; ++q) cur[q] = nxt[q];
+    if (k + 1 < n_int) {
+      const double* __restrict__ dn = d + (n_int - 2 - k) * 22;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) nv1 = nv1 - d[--it] * base[j];
-    base[5] = nv1;
-    double nv2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) nv2 = nv2 - d[--it] * base[j];
-    base[6] = nv2;
-    double nv3 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) nv3 = nv3 - d[--it] * base[j];
+      for (int q = 0; q < 22; ++q) nxt[q] = dn[q];
+    }
+    // reversed iteration over this interval's 22 entries: row k=3 (4 entries, reversed), then
+    // row k=2 (5), k=1 (6), k=0 (7).  Entry order inside a row reversed: the LAST stored entry
+    // multiplies base[0].
+    double v0 = 0.0;
+    v0 = v0 - cur[21] * b0; v0 = v0 - cur[20] * b1; v0 = v0 - cur[19] * b2; v0 = v0 - cur[18] * b3;
+    double v1 = 0.0;
+    v1 = v1 - cur[17] * b0; v1 = v1 - cur[16] * b1; v1 = v1 - cur[15] * b2; v1 = v1 - cur[14] * b3;
+    v1 = v1 - cur[13] * v0;
+    double v2 = 0.0;
+    v2 = v2 - cur[12] * b0; v2 = v2 - cur[11] * b1; v2 = v2 - cur[10] * b2; v2 = v2 - cur[9] * b3;
+    v2 = v2 - cur[8] * v0; v2 = v2 - cur[7] * v1;
+    double v3 = 0.0;
+    v3 = v3 - cur[6] * b0; v3 = v3 - cur[5] * b1; v3 = v3 - cur[4] * b2; v3 = v3 - cur[3] * b3;
+    v3 = v3 - cur[2] * v0; v3 = v3 - cur[1] * v1; v3 = v3 - cur[0] * v2;
     const size_t o = len - (k + 1) * 4 - 1;
-    e[o] = nv0; e[o - 1] = nv1; e[o - 2] = nv2; e[o - 3] = nv3;
-    w[3] = nv0; w[2] = nv1; w[1] = nv2; w[0] = nv3;
+    e[o] = v0; e[o - 1] = v1; e[o - 2] = v2; e[o - 3] = v3;
+    b0 = v0; b1 = v1; b2 = v2; b3 = v3;
   }
   // undo the column pivots of the first interval, last recorded first
   const int s1 = swaps[m * 2 + 1], s0 = swaps[m * 2 + 0];
@@ -286,8 +303,9 @@ hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 63) / 64);
-  if (ell0) eigen_forward_kernel<true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
-  else eigen_forward_kernel<false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
+  const unsigned fblocks = (unsigned)((n + 7) / 8);
+  if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
+  else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   eigen_backsub_kernel<<<blocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);

@@ -18,6 +18,12 @@ static hipError_t launch_fused_v(const LaunchArgs& a) {
   return hipGetLastError();
 }
 template <bool ELL0, bool UNIFORM>
+static hipError_t launch_quad_v(const LaunchArgs& a) {
+  const unsigned blocks = (unsigned)((a.n + 15) / 16);
+  det_quad_kernel<STORM_SCHEME, ELL0, UNIFORM><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
+  return hipGetLastError();
+}
+template <bool ELL0, bool UNIFORM>
 static hipError_t launch_build_v(const LaunchArgs& a) {
   const dim3 grid((unsigned)((a.sys.n_int + 255) / 256), (unsigned)a.n, 1);
   build_steps_kernel<STORM_SCHEME, ELL0, UNIFORM><<<grid, 256, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
@@ -28,6 +34,11 @@ hipError_t STORM_CAT(launch_fused_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   if (a.n == 0 ) return hipSuccess;
   if (a.ell0) return launch_fused_v<true, true>(a);
   return a.uniform ? launch_fused_v<false, true>(a) : launch_fused_v<false, false>(a);
+}
+hipError_t STORM_CAT(launch_quad_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
+  if (a.n == 0) return hipSuccess;
+  if (a.ell0) return launch_quad_v<true, true>(a);
+  return a.uniform ? launch_quad_v<false, true>(a) : launch_quad_v<false, false>(a);
 }
 hipError_t STORM_CAT(launch_build_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   if (a.n == 0 || a.sys.n_int == 0) return hipSuccess;

@@ -20,12 +20,16 @@ namespace storm {
 
 #define STORM_DECL_SCHEME(n)                                 \
   hipError_t launch_fused_scheme_##n(const LaunchArgs&);      \
+  hipError_t launch_quad_scheme_##n(const LaunchArgs&);       \
   hipError_t launch_build_scheme_##n(const LaunchArgs&);
 STORM_DECL_SCHEME(0) STORM_DECL_SCHEME(1) STORM_DECL_SCHEME(2) STORM_DECL_SCHEME(3)
 STORM_DECL_SCHEME(4) STORM_DECL_SCHEME(5) STORM_DECL_SCHEME(6) STORM_DECL_SCHEME(7)
 launch_fn g_launch_fused[kNumSchemes] = {launch_fused_scheme_0, launch_fused_scheme_1, launch_fused_scheme_2,
                                          launch_fused_scheme_3, launch_fused_scheme_4, launch_fused_scheme_5,
                                          launch_fused_scheme_6, launch_fused_scheme_7};
+launch_fn g_launch_quad[kNumSchemes] = {launch_quad_scheme_0, launch_quad_scheme_1, launch_quad_scheme_2,
+                                        launch_quad_scheme_3, launch_quad_scheme_4, launch_quad_scheme_5,
+                                        launch_quad_scheme_6, launch_quad_scheme_7};
 launch_fn g_launch_build[kNumSchemes] = {launch_build_scheme_0, launch_build_scheme_1, launch_build_scheme_2,
                                          launch_build_scheme_3, launch_build_scheme_4, launch_build_scheme_5,
                                          launch_build_scheme_6, launch_build_scheme_7};
@@ -69,17 +73,18 @@ struct storm_solver {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
   DevBuf<int> d_swaps, d_flags;
-  int path = 0;                                  // 0 auto, 1 fused, 2 split
+  int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad
   size_t steps_bytes_max = size_t(4) << 30;
-  size_t fused_min_n = 32768;                    // auto: fused kernel from this batch size on
+  size_t fused_min_n = 49152;                    // auto: lane-per-frequency kernel from this batch size on
+  size_t quad_min_n = 1024;                      // auto: quad kernel from this batch size on
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
   bool profile = false;
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> event_pool;
-  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0};
-  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0};
+  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0};
+  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0};
   std::mutex mu;
 };
 
@@ -211,7 +216,13 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
   if (n == 0) return;
   const size_t n_int = s->sys.n_int;
   const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
-  if (fused) {
+  const bool quad = s->path == 3 || (s->path == 0 && !fused && n >= s->quad_min_n);
+  if (quad) {
+    ScopedTimer t(s, st, STORM_KERNEL_DET_QUAD);
+    hip_check(g_launch_quad[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_quad launch");
+    t.stop();
+    count_launch(s);
+  } else if (fused) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_FUSED);
     hip_check(g_launch_fused[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
     t.stop();
@@ -415,13 +426,16 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     std::lock_guard<std::mutex> lock(s->mu);
     const std::string k(key);
     if (k == "path") {
-      if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "path must be 0, 1 or 2");
+      if (value < 0 || value > 3) fail(STORM_ERR_INVALID_ARGUMENT, "path must be 0, 1, 2 or 3");
       s->path = int(value);
     } else if (k == "steps_bytes_max") {
       if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
       s->steps_bytes_max = size_t(value);
     } else if (k == "profile") {
       s->profile = value != 0;
+    } else if (k == "quad_min_n") {
+      if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "quad_min_n must be >= 0");
+      s->quad_min_n = size_t(value);
     } else if (k == "fused_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "fused_min_n must be >= 0");
       s->fused_min_n = size_t(value);

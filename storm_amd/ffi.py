@@ -76,13 +76,13 @@ def load_library():
     return L
 
 
-KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen"]
+KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad"]
 
 
 def kernel_times(handle, reset=False):
     """{kind: (total_ms, launches)} from HIP events (option "profile" must be on)."""
-    ms = (C.c_double * 4)()
-    cnt = (C.c_uint64 * 4)()
+    ms = (C.c_double * len(KERNEL_KINDS))()
+    cnt = (C.c_uint64 * len(KERNEL_KINDS))()
     _check(load_library().storm_solver_kernel_times(C.c_void_p(handle), ms, cnt, 1 if reset else 0))
     return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
 
