@@ -112,13 +112,18 @@ int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
 /* Per-kernel device time, measured with HIP events recorded on the launch stream around every
  * launch while option "profile" is 1.  ms_out / launches_out have STORM_KERNEL_KINDS entries. */
 enum { STORM_KERNEL_DET_FUSED = 0, STORM_KERNEL_BUILD_STEPS = 1, STORM_KERNEL_CHAIN = 2, STORM_KERNEL_EIGEN = 3,
-       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_KINDS = 5 };
+       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_DET_HEX = 5, STORM_KERNEL_KINDS = 6 };
 int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* launches_out, int reset);
 
-/* Tuning knobs; no effect on results (every path is bit-identical).
+/* Options.  Every "path" is bit-identical; only "arithmetic" = 1 changes results (to rounding).
+ *   "arithmetic": 0 (default) parity build: separate multiply and add in the reference's order, results
+ *                 bit-identical to the reference; 1 fast build: the same expressions with FMA contraction
+ *                 (v_fma_f64), ~2x arithmetic ceiling.  Fast-mode contract (tests/test_hip_fast_mode.py):
+ *                 |det_fast - det_ref| <= 1e-9 * max|det_ref| over the neighbouring grid points, identical
+ *                 sign pattern / bracket indices on the BASELINE configs, roots within 1e-10 relative.
  *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels,
- *           3 force the quad-per-frequency fused kernel
- *   "quad_min_n": batch size from which "path" 0 picks the quad kernel (below: build + ordered product)
+ *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16-lanes-per-frequency fused kernel
+ *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
  *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)
  *   "fused_min_n": batch size from which "path" 0 picks the fused kernel
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */

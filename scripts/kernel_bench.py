@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--fused-n", type=int, default=65536)
 ap.add_argument("--ell", type=int, default=2)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--arith", type=int, default=0)
 args = ap.parse_args()
 
 model = host.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_tams.npz"))
@@ -26,9 +27,10 @@ grid = model.field("r_coord")
 for scheme in args.schemes:
     s = host.ErasedSolver(model, args.ell, 0, scheme, grid)
     s.set_option("profile", 1)
+    s.set_option("arithmetic", args.arith)
     n_int = s.n_int
     out = [f"{scheme:8s}"]
-    for path, n in ((2, args.n), (3, args.n), (3, 4 * args.n), (1, args.fused_n)):
+    for path, n in ((2, args.n), (4, args.n), (4, 10000), (3, 4 * args.n), (1, args.fused_n)):
         f = host.linspace(1.0, 25.0, n)
         s.set_option("path", path)
         s.det(f)
@@ -39,7 +41,7 @@ for scheme in args.schemes:
         for kind, (ms, cnt) in kt.items():
             if cnt:
                 per = ms / args.reps
-                tf = n * n_int * FLOPS[scheme] / (per * 1e-3) / 1e12 if kind in ("build_steps", "det_fused", "det_quad") else 0
+                tf = n * n_int * FLOPS[scheme] / (per * 1e-3) / 1e12 if kind in ("build_steps", "det_fused", "det_quad", "det_hex") else 0
                 gbs = n * n_int * 128 / (per * 1e-3) / 1e9 if kind in ("build_steps", "chain") else 0
                 out.append(f"{kind}[n={n}] {per:8.3f} ms" + (f" {tf:5.1f} TF" if tf else "") + (f" {gbs:6.0f} GB/s" if gbs else ""))
     print(" | ".join(out), flush=True)

@@ -11,8 +11,10 @@
 //                       86-161,271-433).  One lane per mode.
 //   eigen_backsub_kernel  back-substitution to the eigenvector (reference src/solver.rs:100-131).
 #include "common_kernels.hpp"
+#include "device_system.hpp"
 
-namespace storm {
+namespace STORM_NS {
+using namespace storm;
 
 template <int K>
 SDEV double quad_bcast(double x) {
@@ -312,4 +314,4 @@ hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_
   return hipGetLastError();
 }
 
-}  // namespace storm
+}  // namespace STORM_NS

@@ -1,9 +1,13 @@
 #pragma once
-#include "device_system.hpp"
+#include "types.hpp"
 
-namespace storm {
-hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
-                        double* det_out, hipStream_t stream);
-hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
-                        double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream);
-}  // namespace storm
+// Scheme-independent launchers, one set per arithmetic build (see types.hpp).
+#define STORM_DECL_COMMON(ns)                                                                                     \
+  namespace ns {                                                                                                  \
+  hipError_t launch_chain(const storm::SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps, \
+                          double* det_out, hipStream_t stream);                                                   \
+  hipError_t launch_eigen(const storm::SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps, \
+                          double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream);           \
+  }
+STORM_DECL_COMMON(storm)
+STORM_DECL_COMMON(storm_fast)

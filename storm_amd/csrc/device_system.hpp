@@ -12,22 +12,8 @@
 #pragma once
 #include "mat4.hpp"
 
-namespace storm {
-
-enum Field : int {
-  F_M00 = 0, F_M01, F_M10, F_M11, F_M22, F_M30, F_M31, F_M32 /* = dx*lambda */, F_M33,
-  F_D /* dx = delta/x */, F_DC1 /* dx*c1 */, F_DL2 /* (dx*lambda)^2 */, F_ROTM /* m*rot */,
-  kNumFields
-};
-
-struct SystemDev {
-  const double* tab;   // kNumFields planes
-  size_t plane;        // doubles per plane (= p * n_int)
-  size_t n_int;        // grid intervals
-  double ell, lambda;  // lambda = ell*(ell+1)
-  double inner_c1, inner_rotm, outer_u;
-  double rotm_uniform;  // value of every m*rot entry when they are all bitwise equal
-};
+namespace STORM_NS {
+using namespace storm;
 
 // Frequency-dependent scalars of add_frequency.  With a uniform m*rot they are the same at
 // every collocation point, so they are evaluated once per frequency (same operations, same
@@ -185,4 +171,4 @@ SDEV double close_determinant(const SystemDev& s, double f, const M4& accum) {
   return det * B[3][3];
 }
 
-}  // namespace storm
+}  // namespace STORM_NS

@@ -11,10 +11,10 @@
 //     of the input against the first column of cofactors, then multiply by 1/det.
 // Column-major: element (r, c) lives at v[c*4 + r].
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "types.hpp"
 
-namespace storm {
+namespace STORM_NS {
+using namespace storm;
 
 #define SDEV __device__ __forceinline__
 
@@ -192,4 +192,4 @@ SDEV M4 m4_exp(M4 a) {
 
 SDEV M4 m4_commutator(const M4& a, const M4& b) { return m4_sub(m4_mul(a, b), m4_mul(b, a)); }
 
-}  // namespace storm
+}  // namespace STORM_NS

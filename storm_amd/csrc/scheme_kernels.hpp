@@ -16,7 +16,8 @@
 #include "device_system.hpp"
 #include "steppers.hpp"
 
-namespace storm {
+namespace STORM_NS {
+using namespace storm;
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
 SDEV M4 interval_step(const SystemDev& s, size_t i, double f, const FreqTerms& ut, bool& ok) {
@@ -113,6 +114,82 @@ __global__ __launch_bounds__(64) void det_quad_kernel(SystemDev s, const double*
   }
 }
 
+// 16 lanes per frequency ("hex" kernel, 4 frequencies per wave).  Round t: lane s of a group builds
+// the step matrix of interval 16t+s (phase A), parks it row-major in LDS, then the group multiplies
+// the 16 matrices into the running product in interval order (phase B): lane (r, c) owns element
+// (r, c) of the product, reads row r of each step matrix from LDS and gets column c of the product
+// from its quad by DPP.  Element by element this is the reference's gemm (same order as the
+// ordered-product kernel in common_kernels.hip), so results stay bit-identical while one launch
+// exposes n/4 waves.
+constexpr int kHexLaneStride = 18;                       // doubles; 16 + 2 of padding (LDS banks)
+constexpr int kHexGroupStride = 16 * kHexLaneStride + 4;  // doubles
+
+SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
+  const double a0 = quad_bcast_d<0>(acc), a1 = quad_bcast_d<1>(acc), a2 = quad_bcast_d<2>(acc), a3 = quad_bcast_d<3>(acc);
+  double t = lo.x * a0;
+  t = lo.y * a1 + t;
+  t = hi.x * a2 + t;
+  t = hi.y * a3 + t;
+  return t;
+}
+
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64) void det_hex_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+                                                     double* __restrict__ det_out, int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * kHexGroupStride];
+  const int tid = threadIdx.x;
+  const int g = tid >> 4;    // frequency within the wave
+  const int sub = tid & 15;  // interval within the round (phase A) / element c*4+r (phase B)
+  const int r = sub & 3;
+  const int c = sub >> 2;
+  const size_t t = (size_t)blockIdx.x * 4 + g;
+  const double f = freq[t < n ? t : n - 1];
+  const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
+  bool ok = true;
+  double acc = (r == c) ? 1.0 : 0.0;
+  const size_t n_int = s.n_int;
+  double* __restrict__ mine = lds + g * kHexGroupStride + sub * kHexLaneStride;
+  const double* __restrict__ rows = lds + g * kHexGroupStride + r * 4;
+  for (size_t i0 = 0; i0 < n_int; i0 += 16) {
+    const size_t i = i0 + sub;
+    const M4 l = interval_step<SCHEME, ELL0, UNIFORM>(s, i < n_int ? i : n_int - 1, f, ut, ok);
+    __syncthreads();  // previous round's rows have been consumed
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {  // row-major: row rr = {L(rr,0..3)}
+      *reinterpret_cast<double2*>(mine + rr * 4) = make_double2(l.v[0 * 4 + rr], l.v[1 * 4 + rr]);
+      *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
+    }
+    __syncthreads();
+    double2 lo[16], hi[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      lo[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride);
+      hi[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride + 2);
+    }
+    if (i0 + 16 <= n_int) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = hex_chain_step(acc, lo[k], hi[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (i0 + k < n_int) acc = hex_chain_step(acc, lo[k], hi[k]);
+    }
+  }
+  __syncthreads();
+  lds[g * kHexGroupStride + sub] = acc;  // column-major element c*4+r
+  const unsigned long long bad = __ballot(!ok);
+  __syncthreads();
+  if (sub == 0 && t < n) {
+    M4 a;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a.v[e] = lds[g * kHexGroupStride + e];
+    const bool group_ok = ((bad >> (tid & 48)) & 0xffffULL) == 0;
+    const double det = close_determinant<ELL0>(s, f, a);
+    det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
+    if (!group_ok) atomicOr(flags, 1);
+  }
+}
+
 template <int SCHEME, bool ELL0, bool UNIFORM>
 __global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                           double* __restrict__ steps, int* __restrict__ flags) {
@@ -135,19 +212,4 @@ __global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s, const dou
   if (!ok) atomicOr(flags, 1);
 }
 
-// Host-side launchers, one pair per scheme TU (defined in scheme_tu.hip).
-struct LaunchArgs {
-  SystemDev sys;
-  const double* freq;  // device
-  size_t n;
-  double* out;         // det_out (fused) or steps (build), device
-  int* flags;          // device
-  bool ell0, uniform;
-  hipStream_t stream;
-};
-typedef hipError_t (*launch_fn)(const LaunchArgs&);
-extern launch_fn g_launch_fused[kNumSchemes];
-extern launch_fn g_launch_quad[kNumSchemes];
-extern launch_fn g_launch_build[kNumSchemes];
-
-}  // namespace storm
+}  // namespace STORM_NS

@@ -11,16 +11,8 @@
 #pragma once
 #include "mat4.hpp"
 
-namespace storm {
-
-enum Scheme : int {
-  kColloc2 = 0, kColloc4 = 1, kColloc6 = 2, kColloc8 = 3,
-  kMagnus2 = 4, kMagnus4 = 5, kMagnus6 = 6, kMagnus8 = 7,
-  kNumSchemes = 8
-};
-
-__host__ __device__ constexpr int scheme_points(int s) { return (s & 3) + 1; }
-__host__ __device__ constexpr bool scheme_is_magnus(int s) { return s >= kMagnus2; }
+namespace STORM_NS {
+using namespace storm;
 
 // Gauss-Legendre nodes on [-1/2, 1/2] (reference src/stepper.rs:94-105).
 constexpr double kC2_1 = -0.28867513459481287, kC2_2 = 0.28867513459481287;
@@ -163,4 +155,4 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
   }
 }
 
-}  // namespace storm
+}  // namespace STORM_NS

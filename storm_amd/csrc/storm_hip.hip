@@ -14,25 +14,35 @@
 #include <vector>
 
 #include "common_kernels.hpp"
-#include "scheme_kernels.hpp"
+#include "types.hpp"
+
+#define STORM_DECL_SCHEME(ns, n)                                  \
+  namespace ns {                                                  \
+  hipError_t launch_fused_scheme_##n(const storm::LaunchArgs&);   \
+  hipError_t launch_quad_scheme_##n(const storm::LaunchArgs&);    \
+  hipError_t launch_hex_scheme_##n(const storm::LaunchArgs&);     \
+  hipError_t launch_build_scheme_##n(const storm::LaunchArgs&);   \
+  }
+#define STORM_DECL_ALL(ns)                                                                          \
+  STORM_DECL_SCHEME(ns, 0) STORM_DECL_SCHEME(ns, 1) STORM_DECL_SCHEME(ns, 2) STORM_DECL_SCHEME(ns, 3) \
+  STORM_DECL_SCHEME(ns, 4) STORM_DECL_SCHEME(ns, 5) STORM_DECL_SCHEME(ns, 6) STORM_DECL_SCHEME(ns, 7)
+STORM_DECL_ALL(storm)
+STORM_DECL_ALL(storm_fast)
 
 namespace storm {
 
-#define STORM_DECL_SCHEME(n)                                 \
-  hipError_t launch_fused_scheme_##n(const LaunchArgs&);      \
-  hipError_t launch_quad_scheme_##n(const LaunchArgs&);       \
-  hipError_t launch_build_scheme_##n(const LaunchArgs&);
-STORM_DECL_SCHEME(0) STORM_DECL_SCHEME(1) STORM_DECL_SCHEME(2) STORM_DECL_SCHEME(3)
-STORM_DECL_SCHEME(4) STORM_DECL_SCHEME(5) STORM_DECL_SCHEME(6) STORM_DECL_SCHEME(7)
-launch_fn g_launch_fused[kNumSchemes] = {launch_fused_scheme_0, launch_fused_scheme_1, launch_fused_scheme_2,
-                                         launch_fused_scheme_3, launch_fused_scheme_4, launch_fused_scheme_5,
-                                         launch_fused_scheme_6, launch_fused_scheme_7};
-launch_fn g_launch_quad[kNumSchemes] = {launch_quad_scheme_0, launch_quad_scheme_1, launch_quad_scheme_2,
-                                        launch_quad_scheme_3, launch_quad_scheme_4, launch_quad_scheme_5,
-                                        launch_quad_scheme_6, launch_quad_scheme_7};
-launch_fn g_launch_build[kNumSchemes] = {launch_build_scheme_0, launch_build_scheme_1, launch_build_scheme_2,
-                                         launch_build_scheme_3, launch_build_scheme_4, launch_build_scheme_5,
-                                         launch_build_scheme_6, launch_build_scheme_7};
+// [arithmetic: 0 parity, 1 fast][scheme]
+#define STORM_TABLE(kind)                                                                                      \
+  {{storm::launch_##kind##_scheme_0, storm::launch_##kind##_scheme_1, storm::launch_##kind##_scheme_2,           \
+    storm::launch_##kind##_scheme_3, storm::launch_##kind##_scheme_4, storm::launch_##kind##_scheme_5,           \
+    storm::launch_##kind##_scheme_6, storm::launch_##kind##_scheme_7},                                           \
+   {storm_fast::launch_##kind##_scheme_0, storm_fast::launch_##kind##_scheme_1, storm_fast::launch_##kind##_scheme_2, \
+    storm_fast::launch_##kind##_scheme_3, storm_fast::launch_##kind##_scheme_4, storm_fast::launch_##kind##_scheme_5, \
+    storm_fast::launch_##kind##_scheme_6, storm_fast::launch_##kind##_scheme_7}}
+static const launch_fn g_launch_fused[2][kNumSchemes] = STORM_TABLE(fused);
+static const launch_fn g_launch_quad[2][kNumSchemes] = STORM_TABLE(quad);
+static const launch_fn g_launch_hex[2][kNumSchemes] = STORM_TABLE(hex);
+static const launch_fn g_launch_build[2][kNumSchemes] = STORM_TABLE(build);
 
 static thread_local std::string g_error;
 
@@ -73,18 +83,20 @@ struct storm_solver {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
   DevBuf<int> d_swaps, d_flags;
-  int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad
+  int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
+  int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad, 4 hex
   size_t steps_bytes_max = size_t(4) << 30;
   size_t fused_min_n = 49152;                    // auto: lane-per-frequency kernel from this batch size on
-  size_t quad_min_n = 1024;                      // auto: quad kernel from this batch size on
+  size_t quad_min_n = size_t(1) << 62;           // auto: quad kernel from this batch size on (off by default)
+  size_t hex_min_n = 512;                        // auto: 16-lanes-per-frequency kernel from this batch size on
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
   bool profile = false;
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> event_pool;
-  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0};
-  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0};
+  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0};
+  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0};
   std::mutex mu;
 };
 
@@ -217,14 +229,20 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
   const size_t n_int = s->sys.n_int;
   const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
   const bool quad = s->path == 3 || (s->path == 0 && !fused && n >= s->quad_min_n);
-  if (quad) {
+  const bool hex = s->path == 4 || (s->path == 0 && !fused && !quad && n >= s->hex_min_n);
+  if (hex) {
+    ScopedTimer t(s, st, STORM_KERNEL_DET_HEX);
+    hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_hex launch");
+    t.stop();
+    count_launch(s);
+  } else if (quad) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_QUAD);
-    hip_check(g_launch_quad[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_quad launch");
+    hip_check(g_launch_quad[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_quad launch");
     t.stop();
     count_launch(s);
   } else if (fused) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_FUSED);
-    hip_check(g_launch_fused[s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
+    hip_check(g_launch_fused[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
     t.stop();
     count_launch(s);
   } else {
@@ -237,10 +255,10 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
       ScopedTimer tb(s, st, STORM_KERNEL_BUILD_STEPS);
-      hip_check(g_launch_build[s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st)), "build_steps launch");
+      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st)), "build_steps launch");
       tb.stop();
       ScopedTimer tc(s, st, STORM_KERNEL_CHAIN);
-      hip_check(launch_chain(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
+      hip_check((s->arith ? storm_fast::launch_chain : storm::launch_chain)(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
       tc.stop();
       count_launch(s, 2);
     }
@@ -346,7 +364,7 @@ void refine_all(storm_solver* s, std::vector<BracketState>& br, uint64_t ulp) {
 extern "C" {
 
 const char* storm_last_error(void) { return g_error.c_str(); }
-const char* storm_version(void) { return "storm_hip 0.1 (gfx950, parity arithmetic)"; }
+const char* storm_version(void) { return "storm_hip 0.2 (gfx950; arithmetic: parity [default] | fast)"; }
 
 uint64_t storm_precision_relative_to_ulp(double rel) {
   const double q = std::floor(rel / std::numeric_limits<double>::epsilon());
@@ -426,13 +444,19 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     std::lock_guard<std::mutex> lock(s->mu);
     const std::string k(key);
     if (k == "path") {
-      if (value < 0 || value > 3) fail(STORM_ERR_INVALID_ARGUMENT, "path must be 0, 1, 2 or 3");
+      if (value < 0 || value > 4) fail(STORM_ERR_INVALID_ARGUMENT, "path must be 0..4");
       s->path = int(value);
     } else if (k == "steps_bytes_max") {
       if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
       s->steps_bytes_max = size_t(value);
+    } else if (k == "arithmetic") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "arithmetic must be 0 (parity) or 1 (fast)");
+      s->arith = int(value);
     } else if (k == "profile") {
       s->profile = value != 0;
+    } else if (k == "hex_min_n") {
+      if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
+      s->hex_min_n = size_t(value);
     } else if (k == "quad_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "quad_min_n must be >= 0");
       s->quad_min_n = size_t(value);
@@ -549,10 +573,10 @@ int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, doubl
       const size_t m = std::min(chunk, n - off);
       hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
       ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
-      hip_check(g_launch_build[s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
+      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
       tb.stop();
       ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
-      hip_check(launch_eigen(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p, s->d_swaps.p, s->d_det.p,
+      hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p, s->d_swaps.p, s->d_det.p,
                              s->d_vec.p, s->stream), "eigen launch");
       te.stop();
       count_launch(s, 3);

@@ -1,0 +1,51 @@
+// types.hpp -- plain types shared by the host code and by both arithmetic builds of the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// The device code is compiled twice from the same sources:
+//   namespace storm       -ffp-contract=off   separate mul and add: bit-identical to the reference
+//   namespace storm_fast  -ffp-contract=fast  v_fma_f64 allowed: ~2x arithmetic ceiling, results agree
+//                                              with the reference to rounding (tolerances in DESIGN.md)
+#ifndef STORM_NS
+#define STORM_NS storm
+#endif
+
+namespace storm {
+
+enum Scheme : int {
+  kColloc2 = 0, kColloc4 = 1, kColloc6 = 2, kColloc8 = 3,
+  kMagnus2 = 4, kMagnus4 = 5, kMagnus6 = 6, kMagnus8 = 7,
+  kNumSchemes = 8
+};
+__host__ __device__ constexpr int scheme_points(int s) { return (s & 3) + 1; }
+__host__ __device__ constexpr bool scheme_is_magnus(int s) { return s >= kMagnus2; }
+
+enum Field : int {
+  F_M00 = 0, F_M01, F_M10, F_M11, F_M22, F_M30, F_M31, F_M32 /* = dx*lambda */, F_M33,
+  F_D /* dx = delta/x */, F_DC1 /* dx*c1 */, F_DL2 /* (dx*lambda)^2 */, F_ROTM /* m*rot */,
+  kNumFields
+};
+
+struct SystemDev {
+  const double* tab;   // kNumFields planes
+  size_t plane;        // doubles per plane (= p * n_int)
+  size_t n_int;        // grid intervals
+  double ell, lambda;  // lambda = ell*(ell+1)
+  double inner_c1, inner_rotm, outer_u;
+  double rotm_uniform;  // value of every m*rot entry when they are all bitwise equal
+};
+
+struct LaunchArgs {
+  SystemDev sys;
+  const double* freq;  // device
+  size_t n;
+  double* out;         // det_out (fused kernels) or steps (build), device
+  int* flags;          // device
+  bool ell0, uniform;
+  hipStream_t stream;
+};
+typedef hipError_t (*launch_fn)(const LaunchArgs&);
+
+}  // namespace storm

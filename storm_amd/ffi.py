@@ -76,7 +76,7 @@ def load_library():
     return L
 
 
-KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad"]
+KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad", "det_hex"]
 
 
 def kernel_times(handle, reset=False):

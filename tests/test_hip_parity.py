@@ -95,7 +95,7 @@ def test_det_bit_exact_both_paths(oracle, oracle_models, scheme, ell):
     h = hip_from_oracle(o)
     freqs = np.concatenate([oracle.linspace(0.7, 30.0, 61), [3.3047719, 10.0, 24.999]])
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3):
+    for path in (1, 2, 3, 4):
         h.set_option("path", path)
         got = h.det(freqs)
         assert same_bits(ref, got), f"path {path}"
@@ -112,7 +112,7 @@ def test_det_uniform_rotation(oracle, golden_dir, scheme, ell, m):
     h = hip_from_oracle(o)
     freqs = oracle.linspace(1.0, 25.0, 40)
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3):
+    for path in (1, 2, 3, 4):
         h.set_option("path", path)
         assert same_bits(ref, h.det(freqs)), f"path {path}"
 
@@ -127,7 +127,7 @@ def test_det_differential_rotation(oracle, golden_dir, scheme):
     h = hip_from_oracle(o)
     freqs = oracle.linspace(1.0, 20.0, 33)
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3):
+    for path in (1, 2, 3, 4):
         h.set_option("path", path)
         assert same_bits(ref, h.det(freqs)), f"path {path}"
 
@@ -195,7 +195,7 @@ def test_empty_and_tiny_batches(oracle, oracle_models):
     assert res == [] and same_bits(dets, o.det(5.0))
     for n in (1, 2, 3, 5, 63, 64, 65, 130):
         f = oracle.linspace(2.0, 9.0, n) if n > 1 else np.array([2.0])
-        for path in (1, 2, 3):
+        for path in (1, 2, 3, 4):
             h.set_option("path", path)
             assert same_bits(o.det(f, threads=16), h.det(f)), (n, path)
 
@@ -211,7 +211,7 @@ def test_tiny_grids(oracle, npts):
             h = hip_from_oracle(o)
             f = oracle.linspace(1.0, 6.0, 7)
             ref = o.det(f)
-            for path in (1, 2, 3):
+            for path in (1, 2, 3, 4):
                 h.set_option("path", path)
                 assert same_bits(ref, h.det(f)), (scheme, ell, path)
             rdet, rvec = o.eigenvector(f[:3])
@@ -283,7 +283,7 @@ def test_full_size_scan_config2(oracle, golden_dir, scheme, ell):
     ulp = oracle.relative_to_ulp(1e-8)
     gres, gdets, ginv = h.scan_and_optimize(f, ulp)
     # (1) the two kernel paths agree bit for bit on the whole grid
-    for path in (1, 2, 3):
+    for path in (1, 2, 3, 4):
         h.set_option("path", path)
         assert same_bits(gdets, h.det(f)), path
     h.set_option("path", 0)
