@@ -28,9 +28,13 @@ sys.path.insert(0, ROOT)
 # oracle/storm_ref.hpp Counted) for ell != 0 with uniform rotation.  See DESIGN.md.
 FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "colloc8": 5048.1,
                   "magnus2": 1486.0, "magnus4": 1848.0, "magnus6": 2562.0, "magnus8": 3900.1}
+# HBM bytes per launch of the dominant kernels, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+# (profiles/r01_pmc_hbm_traffic_*.txt; raw counters in KB, no width correction applied).
+TRAFFIC = {"det_quad<colloc8>": 9751.69e3 + 78.125e3}
 PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz); = dense FP64 MFMA peak
 
-CASES = [(ell, scheme) for scheme in ("magnus6", "colloc8") for ell in (1, 2, 3)]
+# longest jobs first (colloc8 costs ~2x magnus6) so their latency-bound tails overlap the other scans
+CASES = [(ell, scheme) for scheme in ("colloc8", "magnus6") for ell in (3, 2, 1)]
 N_FREQ_PER_GPU = 10000
 PRECISION = 1e-8
 
@@ -71,6 +75,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=6, help="host threads driving independent scans (1 = sequential)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--arithmetic", choices=["parity", "fast"], default="parity",
+                    help="headline arithmetic: parity = bit-identical to the reference (default); fast = FMA build")
+    ap.add_argument("--single-mode", action="store_true", help="do not also measure the other arithmetic mode")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of N > 1)")
     args = ap.parse_args()
 
     import torch
@@ -80,11 +88,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()  # (rehearsals may oversubscribe one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    coll_device = device if args.dist_backend == "nccl" else torch.device("cpu")
 
     from storm_amd import host, distributed as D
     npz = os.path.join(ROOT, "tests", "golden", "gsm_tams.npz")
@@ -148,7 +161,7 @@ def main():
         modes_global = 0
         for lo, res, inv in parts:
             if world > 1:
-                rec, _ = D.gather_brackets(D.pack(res, lo), inv, device)
+                rec, _ = D.gather_brackets(D.pack(res, lo), inv, coll_device)
                 modes_global += rec.shape[0]
             else:
                 modes_global += len(res)
@@ -159,73 +172,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    for s in solvers:
-        s.stats(reset=True)
-        s.kernel_times(reset=True)
-    sync()
-    t0 = time.perf_counter()
-    modes = 0
-    for _ in range(args.steps):
-        modes = one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    det_evals = sum(s.stats()["det_evals"] for s in solvers)
-    refine = sum(s.stats()["refine_evals"] for s in solvers)
-    eigs = sum(s.stats()["eigenvectors"] for s in solvers)
-    if world > 1:
-        t = torch.tensor([det_evals, refine, eigs], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        det_evals, refine, eigs = (int(x) for x in t.tolist())
-
-    # Per-kernel device time inside the timed region (HIP events on each solver's launch stream).
-    # With six scans in flight these durations overlap each other, so they are reported as they
-    # are but NOT used for the roofline.
-    per_kind = {}
-    for (ell, scheme), s in zip(CASES, solvers):
-        for kind, (ms, cnt) in s.kernel_times().items():
-            if cnt:
-                d = per_kind.setdefault((kind, scheme), {"ms": 0.0, "launches": 0})
-                d["ms"] += ms
-                d["launches"] += cnt
-    kernel_summary = {f"{k}/{sch}": {"ms_total": round(v["ms"], 3), "launches": v["launches"],
-                                      "avg_ms": round(v["ms"] / v["launches"], 4)} for (k, sch), v in per_kind.items()}
-    dom_kind, dom_scheme = max(per_kind.items(), key=lambda kv: kv[1]["ms"])[0]
-
-    # Roofline of the dominant kernel: the same launch (same solver, same 10^4-frequency slice, same
-    # grid) repeated alone on the device, timed with HIP events on the stream it is launched on.
-    roofline = None
-    if rank == 0:
-        k_dom = max((k for k, (ell, sch) in enumerate(CASES) if sch == dom_scheme), key=lambda k: CASES[k][0])
-        sd = solvers[k_dom]
-        lo, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
-        sd.det(mine)
-        sd.kernel_times(reset=True)
-        reps = 5
-        for _ in range(reps):
+    def measure(arith, steps, warmup):
+        """Times `steps` passes in arithmetic mode `arith` (0 parity, 1 fast); returns a dict."""
+        for s in solvers:
+            s.set_option("arithmetic", arith)
+        for _ in range(warmup):
+            one_step()
+        for s in solvers:
+            s.stats(reset=True)
+            s.kernel_times(reset=True)
+        sync()
+        t0 = time.perf_counter()
+        modes = 0
+        for _ in range(steps):
+            modes = one_step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        det_evals = sum(s.stats()["det_evals"] for s in solvers)
+        refine = sum(s.stats()["refine_evals"] for s in solvers)
+        eigs = sum(s.stats()["eigenvectors"] for s in solvers)
+        if world > 1:
+            t = torch.tensor([det_evals, refine, eigs], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            det_evals, refine, eigs = (int(x) for x in t.tolist())
+        # Per-kernel device time inside the timed region (HIP events on each solver's launch stream).
+        # With six scans in flight these durations overlap each other, so they are reported as they
+        # are but NOT used for the roofline.
+        per_kind = {}
+        for (ell, scheme), s in zip(CASES, solvers):
+            for kind, (ms, cnt) in s.kernel_times().items():
+                if cnt:
+                    d = per_kind.setdefault((kind, scheme), {"ms": 0.0, "launches": 0})
+                    d["ms"] += ms
+                    d["launches"] += cnt
+        kernel_summary = {f"{k}/{sch}": {"ms_total": round(v["ms"], 3), "launches": v["launches"],
+                                          "avg_ms": round(v["ms"] / v["launches"], 4)} for (k, sch), v in per_kind.items()}
+        dom_kind, dom_scheme = max(per_kind.items(), key=lambda kv: kv[1]["ms"])[0]
+        # Roofline of the dominant kernel: the same launch (same solver, same frequency slice, same grid)
+        # repeated alone on the device, timed with HIP events on the stream it is launched on.
+        roofline = None
+        if rank == 0:
+            k_dom = max((k for k, (ell, sch) in enumerate(CASES) if sch == dom_scheme), key=lambda k: CASES[k][0])
+            sd = solvers[k_dom]
+            lo, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
             sd.det(mine)
-        kt = {k: v for k, v in sd.kernel_times(reset=True).items() if v[1]}
-        kind = max(kt.items(), key=lambda kv: kv[1][0])[0]
-        ms, cnt = kt[kind]
-        flops_per_rep = len(mine) * n_int * FLOPS_PER_EVAL[dom_scheme]
-        if kind == "build_steps":  # the ordered product (112 flop/eval) runs in the chain kernel
-            flops_per_rep = len(mine) * n_int * (FLOPS_PER_EVAL[dom_scheme] - 112.0)
-        achieved = flops_per_rep * reps / (ms * 1e-3) / 1e12
-        roofline = {"bound": "fp64-valu", "kernel": f"{kind}<{dom_scheme}>", "achieved": round(achieved, 3),
-                    "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt,
-                    "flops_per_launch": flops_per_rep * reps / cnt,
-                    "unfused_issue_ceiling_TFLOPs": 38.1,
-                    "note": "algorithmic un-fused flops (oracle op count x evals per launch) / HIP-event duration of the "
-                            "kernel run alone; arithmetic is the reference's separate mul and add (bit-exact parity), "
-                            "whose measured chip-wide issue ceiling is 38.1 TFLOP/s (tools/fp64_microbench.hip) = 0.485 "
-                            "of the FMA-counted peak; traffic: coefficient planes are L2-resident (see DESIGN.md)"}
+            sd.kernel_times(reset=True)
+            reps = 5
+            for _ in range(reps):
+                sd.det(mine)
+            kt = {k: v for k, v in sd.kernel_times(reset=True).items() if v[1]}
+            kind = max(kt.items(), key=lambda kv: kv[1][0])[0]
+            ms, cnt = kt[kind]
+            flops_per_rep = len(mine) * n_int * FLOPS_PER_EVAL[dom_scheme]
+            if kind == "build_steps":  # the ordered product (112 flop/eval) runs in the chain kernel
+                flops_per_rep = len(mine) * n_int * (FLOPS_PER_EVAL[dom_scheme] - 112.0)
+            achieved = flops_per_rep * reps / (ms * 1e-3) / 1e12
+            roofline = {"bound": "fp64-valu", "kernel": f"{kind}<{dom_scheme}>", "achieved": round(achieved, 3),
+                        "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_TFLOPS, 4),
+                        "traffic": TRAFFIC.get(f"{kind}<{dom_scheme}>"), "avg_launch_ms": round(ms / cnt, 4),
+                        "launches_timed": cnt, "flops_per_launch": flops_per_rep * reps / cnt,
+                        "note": NOTE_FAST if arith else NOTE_PARITY}
+        return {"elapsed": elapsed, "modes": modes, "det_evals": det_evals, "refine": refine, "eigs": eigs,
+                "kernels": kernel_summary, "roofline": roofline}
+
+    NOTE_PARITY = ("algorithmic un-fused flops (oracle op count x evals per launch) / HIP-event duration of the kernel "
+                   "run alone; parity arithmetic = the reference's separate mul and add (bit-exact results), whose "
+                   "measured chip-wide issue ceiling is 38.1 TFLOP/s (tools/fp64_microbench.hip) = 0.485 of the "
+                   "FMA-counted peak; traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/)")
+    NOTE_FAST = ("same kernel built with FMA contraction (option arithmetic=1): results agree with the reference to "
+                 "rounding (tests/test_hip_fast_mode.py: identical bracket indices, roots within 1e-10); algorithmic "
+                 "flops are still the reference's un-fused count")
+    main_arith = 1 if args.arithmetic == "fast" else 0
+    res = measure(main_arith, args.steps, args.warmup)
+    other = measure(1 - main_arith, max(1, min(args.steps, 2)), 1) if not args.single_mode else None
+    elapsed, modes, det_evals, refine, eigs = res["elapsed"], res["modes"], res["det_evals"], res["refine"], res["eigs"]
+    kernel_summary, roofline = res["kernels"], res["roofline"]
 
     if rank == 0:
         value = det_evals * n_int / elapsed
@@ -240,8 +265,15 @@ def main():
                        "parallelism": f"freq-slice x{world}", "concurrent_scans": args.threads if args.threads > 1 else 1},
             "modes_per_s": modes * args.steps / elapsed if False else (eigs / elapsed),
             "modes_per_step": modes, "det_evals": det_evals, "refine_evals": refine,
-            "kernels": kernel_summary, "roofline": roofline,
+            "arithmetic": args.arithmetic, "kernels": kernel_summary, "roofline": roofline,
         }
+        if other is not None:
+            oname = "parity" if main_arith else "fast"
+            out[f"{oname}_arithmetic"] = {
+                "value": other["det_evals"] * n_int / other["elapsed"], "unit": "freq*interval evals/s",
+                "ms_per_step": other["elapsed"] / max(1, min(args.steps, 2)) * 1e3,
+                "modes_per_s": other["eigs"] / other["elapsed"], "modes_per_step": other["modes"],
+                "roofline": other["roofline"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(npz, args.cpu_budget)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -244,73 +244,91 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
 }
 
 // Back-substitution.  `upper` is walked backwards exactly like the reference's reversed
-// iterator; e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.  One lane per
-// mode; the 22 factors of the next interval are prefetched while the current one is consumed.
+// iterator; e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.
+// One wave per mode: all 64 lanes stream the packed factors of the next kBsTile intervals into LDS
+// (coalesced, one tile ahead of the consumer) and flush finished eigenvector components back out;
+// every lane runs the same short recurrence redundantly on wave-uniform data read from LDS, so no
+// cross-lane traffic sits on the serial chain.
+constexpr int kBsTile = 32;  // intervals per LDS tile
+
 __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
                                                            const int* __restrict__ swaps, double* __restrict__ vec) {
-  const size_t m = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (m >= n) return;
+  __shared__ double fac[2][kBsTile * 22];
+  __shared__ double outb[kBsTile * 4];
+  const size_t m = blockIdx.x;
+  const int lane = threadIdx.x;
   const size_t ustride = n_int * 22 + 6;
   const size_t len = (n_int + 1) * 4;
   const double* __restrict__ d = upper + m * ustride;
   double* __restrict__ e = vec + m * len;
-  e[len - 1] = 1.0;
   // closing 4x4 (reference src/solver.rs:107-113): packed rows {k=0: 3, k=1: 2, k=2: 1 entries}
   const double* __restrict__ df = d + n_int * 22;
   const double e3 = 1.0;
   const double e2 = 0.0 - df[5] * e3;
   const double e1 = (0.0 - df[4] * e3) - df[3] * e2;
   const double e0 = ((0.0 - df[2] * e3) - df[1] * e2) - df[0] * e1;
-  e[len - 2] = e2; e[len - 3] = e1; e[len - 4] = e0;
-  // base[0..3] = components of the grid point to the right, last component first
+  if (lane == 0) { e[len - 1] = e3; e[len - 2] = e2; e[len - 3] = e1; e[len - 4] = e0; }
   double b0 = e3, b1 = e2, b2 = e1, b3 = e0;
-  double cur[22], nxt[22];
-  if (n_int > 0) {
-#pragma unroll
-    for (int q = 0; q < 22; ++q) nxt[q] = d[(n_int - 1) * 22 + q];
-  }
-  for (size_t k = 0; k < n_int; ++k) {
-#pragma unroll
-    for (int q = 0; q < 22; ++q) cur[q] = nxt[q];
-    if (k + 1 < n_int) {
-      const double* __restrict__ dn = d + (n_int - 2 - k) * 22;
-#pragma unroll
-      for (int q = 0; q < 22; ++q) nxt[q] = dn[q];
+  // tiles are taken from the END of the interval range: tile t covers intervals [hi - cnt, hi)
+  const size_t n_tiles = (n_int + kBsTile - 1) / kBsTile;
+  auto tile_bounds = [&](size_t t, size_t& lo, size_t& cnt) {
+    const size_t hi = n_int - t * kBsTile;
+    cnt = hi < (size_t)kBsTile ? hi : (size_t)kBsTile;
+    lo = hi - cnt;
+  };
+  auto load_tile = [&](size_t t, double* dst) {
+    size_t lo, cnt;
+    tile_bounds(t, lo, cnt);
+    const double* src = d + lo * 22;
+    for (size_t q = lane; q < cnt * 22; q += 64) dst[q] = src[q];
+  };
+  if (n_tiles > 0) load_tile(0, fac[0]);
+  __syncthreads();
+  for (size_t t = 0; t < n_tiles; ++t) {
+    if (t + 1 < n_tiles) load_tile(t + 1, fac[(t + 1) & 1]);
+    size_t lo, cnt;
+    tile_bounds(t, lo, cnt);
+    const double* __restrict__ cur_tile = fac[t & 1];
+    for (size_t k = cnt; k-- > 0;) {
+      const double* __restrict__ cur = cur_tile + k * 22;
+      // reversed iteration over this interval's 22 entries: row k=3 (4 entries, reversed), then
+      // row k=2 (5), k=1 (6), k=0 (7); the LAST stored entry of a row multiplies the newest-but-3 value.
+      double v0 = 0.0;
+      v0 = v0 - cur[21] * b0; v0 = v0 - cur[20] * b1; v0 = v0 - cur[19] * b2; v0 = v0 - cur[18] * b3;
+      double v1 = 0.0;
+      v1 = v1 - cur[17] * b0; v1 = v1 - cur[16] * b1; v1 = v1 - cur[15] * b2; v1 = v1 - cur[14] * b3;
+      v1 = v1 - cur[13] * v0;
+      double v2 = 0.0;
+      v2 = v2 - cur[12] * b0; v2 = v2 - cur[11] * b1; v2 = v2 - cur[10] * b2; v2 = v2 - cur[9] * b3;
+      v2 = v2 - cur[8] * v0; v2 = v2 - cur[7] * v1;
+      double v3 = 0.0;
+      v3 = v3 - cur[6] * b0; v3 = v3 - cur[5] * b1; v3 = v3 - cur[4] * b2; v3 = v3 - cur[3] * b3;
+      v3 = v3 - cur[2] * v0; v3 = v3 - cur[1] * v1; v3 = v3 - cur[0] * v2;
+      // components of grid point (lo + k): y1..y4 = v3, v2, v1, v0
+      if (lane == 0) { outb[k * 4 + 0] = v3; outb[k * 4 + 1] = v2; outb[k * 4 + 2] = v1; outb[k * 4 + 3] = v0; }
+      b0 = v0; b1 = v1; b2 = v2; b3 = v3;
     }
-    // reversed iteration over this interval's 22 entries: row k=3 (4 entries, reversed), then
-    // row k=2 (5), k=1 (6), k=0 (7).  Entry order inside a row reversed: the LAST stored entry
-    // multiplies base[0].
-    double v0 = 0.0;
-    v0 = v0 - cur[21] * b0; v0 = v0 - cur[20] * b1; v0 = v0 - cur[19] * b2; v0 = v0 - cur[18] * b3;
-    double v1 = 0.0;
-    v1 = v1 - cur[17] * b0; v1 = v1 - cur[16] * b1; v1 = v1 - cur[15] * b2; v1 = v1 - cur[14] * b3;
-    v1 = v1 - cur[13] * v0;
-    double v2 = 0.0;
-    v2 = v2 - cur[12] * b0; v2 = v2 - cur[11] * b1; v2 = v2 - cur[10] * b2; v2 = v2 - cur[9] * b3;
-    v2 = v2 - cur[8] * v0; v2 = v2 - cur[7] * v1;
-    double v3 = 0.0;
-    v3 = v3 - cur[6] * b0; v3 = v3 - cur[5] * b1; v3 = v3 - cur[4] * b2; v3 = v3 - cur[3] * b3;
-    v3 = v3 - cur[2] * v0; v3 = v3 - cur[1] * v1; v3 = v3 - cur[0] * v2;
-    const size_t o = len - (k + 1) * 4 - 1;
-    e[o] = v0; e[o - 1] = v1; e[o - 2] = v2; e[o - 3] = v3;
-    b0 = v0; b1 = v1; b2 = v2; b3 = v3;
+    __syncthreads();
+    for (size_t q = lane; q < cnt * 4; q += 64) e[lo * 4 + q] = outb[q];
+    __syncthreads();
   }
   // undo the column pivots of the first interval, last recorded first
-  const int s1 = swaps[m * 2 + 1], s0 = swaps[m * 2 + 0];
-  if (s1 != 1) { const double a = e[s1], b = e[1]; e[s1] = b; e[1] = a; }
-  if (s0 != 0) { const double a = e[s0], b = e[0]; e[s0] = b; e[0] = a; }
+  if (lane == 0) {
+    const int s1 = swaps[m * 2 + 1], s0 = swaps[m * 2 + 0];
+    if (s1 != 1) { const double a = e[s1], b = e[1]; e[s1] = b; e[1] = a; }
+    if (s0 != 0) { const double a = e[s0], b = e[0]; e[s0] = b; e[0] = a; }
+  }
 }
 
 hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  const unsigned blocks = (unsigned)((n + 63) / 64);
   const unsigned fblocks = (unsigned)((n + 7) / 8);
   if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
   else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  eigen_backsub_kernel<<<blocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
+  eigen_backsub_kernel<<<(unsigned)n, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
   return hipGetLastError();
 }
 
