@@ -94,24 +94,27 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
 }
 
 // ---------------------------------------------------------------------------------------
-// Eigenvector: forward elimination, 8 lanes per mode.
-// Lane j of a group owns system column j of the 6x8 band (6 values).  For pivot K the owner's
-// column is broadcast to the group and every lane redoes the (tiny) pivot search, so all lanes
-// agree on the row swap and the multipliers without further traffic; each lane then updates its
-// own column.  Arithmetic per entry is exactly the reference's (row_pivot!/column_pivot!/sweep!,
-// src/solver.rs:163-269): m = B[r][K] * (1/pivot); B[r][j] -= prow[j] * m.
+// Eigenvector: forward elimination, one wave per mode.
+// Lane j < 8 owns system column j of the 6x8 band (6 values).  For pivot K the owner's column is
+// read into scalar registers with v_readlane, so the pivot search, the row choice and the
+// multipliers are wave-uniform: the row exchange is a uniform branch (no per-lane selects) and
+// nothing but the readlane sits between two pivots.  Arithmetic per entry is exactly the
+// reference's (row_pivot!/column_pivot!/sweep!, src/solver.rs:163-269):
+//   m = B[r][K] * (1/pivot);  B[r][j] -= prow[j] * m.
 // ---------------------------------------------------------------------------------------
-SDEV double group_bcast(double x, int src) {  // value of lane `src` (0..7) of this 8-lane group
-  return __shfl(x, src, 8);
+SDEV double lane_value(double x, int lane) {  // wave-uniform copy of lane `lane`'s value
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
 }
 
 // ROWS x COLS elimination step K on column-distributed data.  `b` = this lane's column.
 // `up_base` points at the packed upper row of this pivot; lane j > K stores prow*pinv at [j-K-1].
 template <int ROWS, int COLS, int K>
-SDEV void group_pivot(double (&b)[6], int j, double& det, double* __restrict__ up_base, bool search_rows) {
+SDEV void wave_pivot(double (&b)[6], int j, double& det, double* __restrict__ up_base, bool search_rows) {
   double ck[6];
 #pragma unroll
-  for (int r = K; r < ROWS; ++r) ck[r] = group_bcast(b[r], K);
+  for (int r = K; r < ROWS; ++r) ck[r] = lane_value(b[r], K);
   int max_idx = K;
   if (search_rows) {
     double max_val = __builtin_fabs(ck[K]);
@@ -120,17 +123,18 @@ SDEV void group_pivot(double (&b)[6], int j, double& det, double* __restrict__ u
       const double v = __builtin_fabs(ck[r]);
       if (v > max_val) { max_idx = r; max_val = v; }
     }
+    max_idx = __builtin_amdgcn_readfirstlane(max_idx);
   }
   double prow = b[K];
   double pivot = ck[K];
 #pragma unroll
   for (int r = K + 1; r < ROWS; ++r) {
-    const bool sel = (r == max_idx);
-    const double old = b[r], oldc = ck[r];
-    prow = sel ? old : prow;
-    pivot = sel ? oldc : pivot;
-    b[r] = sel ? b[K] : old;
-    ck[r] = sel ? ck[K] : oldc;
+    if (max_idx == r) {  // wave-uniform
+      prow = b[r];
+      pivot = ck[r];
+      b[r] = b[K];
+      ck[r] = ck[K];
+    }
   }
   if (max_idx != K) det = det * -1.0;
   det = det * pivot;
@@ -146,18 +150,23 @@ SDEV void group_pivot(double (&b)[6], int j, double& det, double* __restrict__ u
 // column_pivot! (src/solver.rs:192-230) for pivot K of the first interval: pick the largest entry
 // of system row K among columns K..7, exchange the two columns in rows K..5.
 template <int K>
-SDEV int group_column_swap(double (&b)[6], int j, double& det) {
+SDEV int wave_column_swap(double (&b)[6], int j, double& det) {
   int max_idx = K;
-  double max_val = __builtin_fabs(group_bcast(b[K], K));
+  double max_val = __builtin_fabs(lane_value(b[K], K));
 #pragma unroll
   for (int i = K + 1; i < 8; ++i) {
-    const double v = __builtin_fabs(group_bcast(b[K], i));
+    const double v = __builtin_fabs(lane_value(b[K], i));
     if (v > max_val) { max_idx = i; max_val = v; }
   }
-  const int src = (j == K) ? max_idx : ((j == max_idx) ? K : j);
+  max_idx = __builtin_amdgcn_readfirstlane(max_idx);
+  if (max_idx != K) {
 #pragma unroll
-  for (int r = K; r < 6; ++r) b[r] = group_bcast(b[r], src);
-  if (max_idx != K) det = det * -1.0;
+    for (int r = K; r < 6; ++r) {
+      const double from_max = lane_value(b[r], max_idx), from_k = lane_value(b[r], K);
+      b[r] = (j == K) ? from_max : ((j == max_idx) ? from_k : b[r]);
+    }
+    det = det * -1.0;
+  }
   return max_idx;
 }
 
@@ -168,10 +177,8 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
                                                            const double* __restrict__ steps,
                                                            double* __restrict__ upper, int* __restrict__ swaps,
                                                            double* __restrict__ det_out) {
-  const int tid = threadIdx.x;
-  const int j = tid & 7;
-  const size_t m_raw = (size_t)blockIdx.x * 8 + (tid >> 3);
-  const size_t m = m_raw < n ? m_raw : n - 1;  // surplus groups shadow the last mode (their stores are identical)
+  const int j = threadIdx.x;   // lanes 0..7 carry the band; the others idle along (their values are never used)
+  const size_t m = blockIdx.x;  // one wave per mode
   const double f = freq[m];
   const size_t n_int = s.n_int;
   const size_t ustride = n_int * 22 + 6;
@@ -214,16 +221,16 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
         for (int r = 0; r < 4; ++r) b[r + 2] = (j < 4) ? cur[u][r] : ((j - 4 == r) ? -1.0 : 0.0);
         double* __restrict__ upi = up + i * 22;
         if (i == 0) {
-          sw0 = group_column_swap<0>(b, j, det);
-          group_pivot<6, 8, 0>(b, j, det, upi + 0, false);
-          sw1 = group_column_swap<1>(b, j, det);
-          group_pivot<6, 8, 1>(b, j, det, upi + 7, false);
+          sw0 = wave_column_swap<0>(b, j, det);
+          wave_pivot<6, 8, 0>(b, j, det, upi + 0, false);
+          sw1 = wave_column_swap<1>(b, j, det);
+          wave_pivot<6, 8, 1>(b, j, det, upi + 7, false);
         } else {
-          group_pivot<6, 8, 0>(b, j, det, upi + 0, true);
-          group_pivot<6, 8, 1>(b, j, det, upi + 7, true);
+          wave_pivot<6, 8, 0>(b, j, det, upi + 0, true);
+          wave_pivot<6, 8, 1>(b, j, det, upi + 7, true);
         }
-        group_pivot<6, 8, 2>(b, j, det, upi + 13, true);
-        group_pivot<6, 8, 3>(b, j, det, upi + 18, true);
+        wave_pivot<6, 8, 2>(b, j, det, upi + 13, true);
+        wave_pivot<6, 8, 3>(b, j, det, upi + 18, true);
         // the two untouched rows move up: B[i][j] = B[i+4][j+4], right half cleared
         const double t4 = __shfl_down(b[4], 4, 8), t5 = __shfl_down(b[5], 4, 8);
         b[0] = (j < 4) ? t4 : 0.0;
@@ -231,16 +238,16 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
       }
     }
   }
-  if (j == 0 && m_raw < n) { swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1; }
+  if (j == 0) { swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1; }
   // outer boundary rows (reference src/system/adiabatic.rs:185-208) and the closing 4x4
   b[2] = (j == 0) ? 1.0 : ((j == 1) ? -1.0 : 0.0);
   b[3] = (j == 0) ? s.outer_u : ((j == 2) ? s.ell + 1.0 : ((j == 3) ? 1.0 : 0.0));
   double* __restrict__ uf = up + n_int * 22;
-  group_pivot<4, 4, 0>(b, j, det, uf + 0, true);
-  group_pivot<4, 4, 1>(b, j, det, uf + 3, true);
-  group_pivot<4, 4, 2>(b, j, det, uf + 5, true);
-  const double last = group_bcast(b[3], 3);
-  if (j == 0 && m_raw < n) det_out[m] = det * last;
+  wave_pivot<4, 4, 0>(b, j, det, uf + 0, true);
+  wave_pivot<4, 4, 1>(b, j, det, uf + 3, true);
+  wave_pivot<4, 4, 2>(b, j, det, uf + 5, true);
+  const double last = lane_value(b[3], 3);
+  if (j == 0) det_out[m] = det * last;
 }
 
 // Back-substitution.  `upper` is walked backwards exactly like the reference's reversed
@@ -254,7 +261,6 @@ constexpr int kBsTile = 32;  // intervals per LDS tile
 __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
                                                            const int* __restrict__ swaps, double* __restrict__ vec) {
   __shared__ double fac[2][kBsTile * 22];
-  __shared__ double outb[kBsTile * 4];
   const size_t m = blockIdx.x;
   const int lane = threadIdx.x;
   const size_t ustride = n_int * 22 + 6;
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
     size_t lo, cnt;
     tile_bounds(t, lo, cnt);
     const double* __restrict__ cur_tile = fac[t & 1];
+#pragma unroll 4
     for (size_t k = cnt; k-- > 0;) {
       const double* __restrict__ cur = cur_tile + k * 22;
       // reversed iteration over this interval's 22 entries: row k=3 (4 entries, reversed), then
@@ -305,12 +312,14 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
       v3 = v3 - cur[6] * b0; v3 = v3 - cur[5] * b1; v3 = v3 - cur[4] * b2; v3 = v3 - cur[3] * b3;
       v3 = v3 - cur[2] * v0; v3 = v3 - cur[1] * v1; v3 = v3 - cur[0] * v2;
       // components of grid point (lo + k): y1..y4 = v3, v2, v1, v0
-      if (lane == 0) { outb[k * 4 + 0] = v3; outb[k * 4 + 1] = v2; outb[k * 4 + 2] = v1; outb[k * 4 + 3] = v0; }
+      if (lane == 0) {
+        double2* __restrict__ dst = reinterpret_cast<double2*>(e + (lo + k) * 4);
+        dst[0] = make_double2(v3, v2);
+        dst[1] = make_double2(v1, v0);
+      }
       b0 = v0; b1 = v1; b2 = v2; b3 = v3;
     }
-    __syncthreads();
-    for (size_t q = lane; q < cnt * 4; q += 64) e[lo * 4 + q] = outb[q];
-    __syncthreads();
+    __syncthreads();  // everyone is done with fac[t & 1] before it is refilled two tiles later
   }
   // undo the column pivots of the first interval, last recorded first
   if (lane == 0) {
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
 hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  const unsigned fblocks = (unsigned)((n + 7) / 8);
+  const unsigned fblocks = (unsigned)n;  // one wave per mode
   if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
   else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
   hipError_t e = hipGetLastError();

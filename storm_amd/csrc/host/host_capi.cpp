@@ -121,8 +121,7 @@ int storm_host_solver_scan_and_optimize(void* s, const double* f, size_t n, int 
 }
 int storm_host_solver_eigenvectors(void* s, const double* f, size_t n, double* out) {
   return guarded([&] {
-    std::vector<double> r = static_cast<ErasedSolver*>(s)->eigenvectors(std::vector<double>(f, f + n));
-    std::memcpy(out, r.data(), r.size() * sizeof(double));
+    static_cast<ErasedSolver*>(s)->eigenvectors_into(f, n, out);
   });
 }
 

@@ -301,6 +301,10 @@ std::vector<double> ErasedSolver::eigenvectors(const std::vector<double>& freqs)
   if (rc != STORM_OK) raise_abi("storm_eigenvector_batch", rc);
   return out;
 }
+void ErasedSolver::eigenvectors_into(const double* freqs, size_t n, double* out) const {
+  const int rc = storm_eigenvector_batch(h_, freqs, n, nullptr, out);
+  if (rc != STORM_OK) raise_abi("storm_eigenvector_batch", rc);
+}
 std::vector<BracketResult> ErasedSolver::scan_and_optimize(const std::vector<double>& grid, Precision precision,
                                                            bool* had_invalid) const {
   std::vector<storm_bracket> raw(grid.size() ? grid.size() : 1);

@@ -127,6 +127,8 @@ class ErasedSolver {  // dynamic_interface.rs:60-160
   std::vector<double> eigenvector(double freq) const;
   // Batched form of the per-mode loop of StormState::scan (main.rs:824-831); row-major [n][(n_int+1)*4].
   std::vector<double> eigenvectors(const std::vector<double>& freqs) const;
+  // same, into caller-owned storage of n*(len()+1)*4 doubles (no intermediate copy)
+  void eigenvectors_into(const double* freqs, size_t n, double* out) const;
   std::vector<BracketResult> scan_and_optimize(const std::vector<double>& freq_grid, Precision precision,
                                                bool* had_invalid_numbers = nullptr) const;
   size_t len() const { return n_int_; }
