@@ -400,10 +400,15 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
     s->tab.reserve(tab.size() ? tab.size() : 1);
     hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+    // Uploads are ordered on the solver's own (non-blocking) stream: a plain hipMemcpy from pageable
+    // memory is only ordered against the NULL stream, so a kernel launched on s->stream right after
+    // create could otherwise read the planes before the DMA has landed.
     if (!tab.empty())
-      hip_check(hipMemcpy(s->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice), "planes H2D");
+      hip_check(hipMemcpyAsync(s->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
+                "planes H2D");
     s->d_flags.reserve(1);
-    hip_check(hipMemset(s->d_flags.p, 0, sizeof(int)), "flags memset");
+    hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags memset");
+    hip_check(hipStreamSynchronize(s->stream), "create sync");
     s->sys.tab = s->tab.p;
     s->sys.plane = d->n_int * d->p;
     s->sys.n_int = d->n_int;
