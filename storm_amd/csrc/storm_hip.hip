@@ -70,6 +70,20 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Growable pinned host buffer (staging for large device-to-host results).
+struct PinnedBuf {
+  double* p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) hip_check(hipHostFree(p), "hipHostFree");
+    p = nullptr; cap = 0;
+    hip_check(hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(double), hipHostMallocDefault), "hipHostMalloc");
+    cap = n;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace storm
 
 using namespace storm;
@@ -83,6 +97,7 @@ struct storm_solver {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
   DevBuf<int> d_swaps, d_flags;
+  PinnedBuf h_vec;
   int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
   int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad, 4 hex
   size_t steps_bytes_max = size_t(4) << 30;
@@ -436,7 +451,7 @@ void storm_solver_destroy(storm_solver* s) {
   for (auto& t : s->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
   s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
-  s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release();
+  s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release();
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -585,10 +600,12 @@ int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, doubl
                              s->d_vec.p, s->stream), "eigen launch");
       te.stop();
       count_launch(s, 3);
-      hip_check(hipMemcpyAsync(vec_out + off * len, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
+      s->h_vec.reserve(m * len);
+      hip_check(hipMemcpyAsync(s->h_vec.p, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
       if (det_out)
         hip_check(hipMemcpyAsync(det_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
       check_flags(s);
+      std::memcpy(vec_out + off * len, s->h_vec.p, m * len * sizeof(double));
       s->stats.eigenvectors += m;
     }
   });
