@@ -133,8 +133,14 @@ SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
   return t;
 }
 
+// Magnus 2/4/6 need just over 256 registers when left alone; capping them at 256 buys a second wave
+// per SIMD (better issue utilisation, phase-B latency hidden behind the other wave's phase A).
+__host__ __device__ constexpr int hex_min_waves(int scheme) {
+  return (scheme == kMagnus2 || scheme == kMagnus4 || scheme == kMagnus6) ? 2 : 1;
+}
+
 template <int SCHEME, bool ELL0, bool UNIFORM>
-__global__ __launch_bounds__(64) void det_hex_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                      double* __restrict__ det_out, int* __restrict__ flags) {
   __shared__ __attribute__((aligned(16))) double lds[4 * kHexGroupStride];
   const int tid = threadIdx.x;

@@ -101,7 +101,8 @@ struct storm_solver {
   int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
   int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad, 4 hex
   size_t steps_bytes_max = size_t(4) << 30;
-  size_t fused_min_n = 49152;                    // auto: lane-per-frequency kernel from this batch size on
+  size_t fused_min_n = size_t(1) << 62;          // auto: lane-per-frequency kernel from this batch size on (off: the
+                                                 // 16-lane kernel is faster at every size measured)
   size_t quad_min_n = size_t(1) << 62;           // auto: quad kernel from this batch size on (off by default)
   size_t hex_min_n = 512;                        // auto: 16-lanes-per-frequency kernel from this batch size on
   storm_stats stats{};
