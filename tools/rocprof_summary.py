@@ -15,13 +15,13 @@ NAMES = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magn
 
 def short(name):
     name = re.sub(r"\.kd$", "", name)
-    m = re.match(r"(?:void )?storm::(\w+)(?:<([^>]*)>)?\(", name)
+    m = re.match(r"(?:void )?storm(_fast)?::(\w+)(?:<([^>]*)>)?\(", name)
     if m:  # demangled
-        targs = [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
+        targs = [a.strip() for a in (m.group(3) or "").split(",") if a.strip()]
         if targs and targs[0].isdigit():
             targs[0] = NAMES[int(targs[0])]
         targs = [{"true": "1", "false": "0"}.get(a, a) for a in targs]
-        return m.group(1) + (f"<{','.join(targs)}>" if targs else "")
+        return ("fast:" if m.group(1) else "") + m.group(2) + (f"<{','.join(targs)}>" if targs else "")
     m = re.match(r"_ZN5storm(\d+)(\w+)", name)
     if m:
         n = int(m.group(1))
