@@ -30,7 +30,7 @@ for scheme in args.schemes:
     s.set_option("arithmetic", args.arith)
     n_int = s.n_int
     out = [f"{scheme:8s}"]
-    for path, n in ((4, args.n), (4, 2 * args.n), (4, 10000), (4, 4 * args.n), (1, args.fused_n)):
+    for path, n in ((4, args.n), (4, 10000), (4, 4 * args.n)):
         f = host.linspace(1.0, 25.0, n)
         s.set_option("path", path)
         s.det(f)
