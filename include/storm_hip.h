@@ -122,7 +122,9 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *                 |det_fast - det_ref| <= 1e-9 * max|det_ref| over the neighbouring grid points, identical
  *                 sign pattern / bracket indices on the BASELINE configs, roots within 1e-10 relative.
  *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels,
- *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16-lanes-per-frequency fused kernel
+ *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16/32-lanes-per-frequency fused kernel
+ *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default) the one whose wave count packs the
+ *                GPU's wave slots better for this batch, 16, or 32
  *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
  *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)
  *   "fused_min_n": batch size from which "path" 0 picks the fused kernel

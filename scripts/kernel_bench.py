@@ -20,6 +20,7 @@ ap.add_argument("--fused-n", type=int, default=65536)
 ap.add_argument("--ell", type=int, default=2)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--arith", type=int, default=0)
+ap.add_argument("--lanes", type=int, default=0)
 args = ap.parse_args()
 
 model = host.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_tams.npz"))
@@ -28,6 +29,7 @@ for scheme in args.schemes:
     s = host.ErasedSolver(model, args.ell, 0, scheme, grid)
     s.set_option("profile", 1)
     s.set_option("arithmetic", args.arith)
+    s.set_option("hex_lanes", args.lanes)
     n_int = s.n_int
     out = [f"{scheme:8s}"]
     for path, n in ((4, args.n), (4, 10000), (4, 4 * args.n)):

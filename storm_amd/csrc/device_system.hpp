@@ -2,7 +2,8 @@
 //
 // HBM layout (built once per solver by storm_solver_create, see storm_hip.cpp):
 //   tab[field][point j][interval i]   FP64, field-major SoA, kNumFields planes of `plane` doubles,
-//                                     element (j, i) of a plane at j*n_int + i.
+//                                     element (j, i) of a plane at j*stride + i (stride = n_int padded to
+//                                     a multiple of 16, plus 16: rows start 128-B aligned).
 // A wave whose lanes walk consecutive intervals reads each plane fully coalesced; a wave whose
 // lanes share the interval (lane-per-frequency kernels) reads it through the scalar unit.
 // The planes hold the frequency-independent part of the 4x4 coefficient matrix
@@ -45,39 +46,50 @@ SDEV FreqTerms freq_terms(double f, double rotm, double lambda) {
   return t;
 }
 
-// A_j(omega) of collocation point (j, i): cached part + add_frequency.
-template <bool ELL0, bool UNIFORM>
-SDEV M4 point_matrix(const SystemDev& s, size_t idx, double f, const FreqTerms& ut) {
-  const double* __restrict__ t = s.tab;
-  const size_t pl = s.plane;
+// Where a kernel takes its coefficients from: straight from the planes in global memory ...
+struct GlobalCoef {
+  const double* __restrict__ base;  // tab + i
+  size_t plane, stride;
+  SDEV double operator()(int field, int j) const { return base[field * plane + j * stride]; }
+};
+// ... or from a tile the wave staged in LDS: rows (field*P + j) of W intervals, this lane's interval `sub`.
+template <int P, int W>
+struct LdsCoef {
+  const double* base;  // tile + sub
+  SDEV double operator()(int field, int j) const { return base[(field * P + j) * W]; }
+};
+
+// A_j(omega) of collocation point j of this lane's interval: cached part + add_frequency.
+template <bool ELL0, bool UNIFORM, class Coef>
+SDEV M4 point_matrix(const Coef& t, int j, double lambda, double f, const FreqTerms& ut) {
   M4 a;
 #pragma unroll
   for (int e = 0; e < 16; ++e) a.v[e] = 0.0;
-  const double d = t[F_D * pl + idx];
-  const double dc1 = t[F_DC1 * pl + idx];
-  const double m10 = t[F_M10 * pl + idx];
-  a.v[0 * 4 + 3] = t[F_M30 * pl + idx];
-  a.v[1 * 4 + 3] = t[F_M31 * pl + idx];
-  a.v[2 * 4 + 2] = t[F_M22 * pl + idx];
-  a.v[2 * 4 + 3] = t[F_M32 * pl + idx];
+  const double d = t(F_D, j);
+  const double dc1 = t(F_DC1, j);
+  const double m10 = t(F_M10, j);
+  a.v[0 * 4 + 3] = t(F_M30, j);
+  a.v[1 * 4 + 3] = t(F_M31, j);
+  a.v[2 * 4 + 2] = t(F_M22, j);
+  a.v[2 * 4 + 3] = t(F_M32, j);
   a.v[3 * 4 + 1] = -d;
   a.v[3 * 4 + 2] = d;
-  a.v[3 * 4 + 3] = t[F_M33 * pl + idx];
+  a.v[3 * 4 + 3] = t(F_M33, j);
   if constexpr (ELL0) {
-    a.v[0 * 4 + 0] = t[F_M00 * pl + idx];
-    a.v[1 * 4 + 0] = t[F_M01 * pl + idx];
-    a.v[1 * 4 + 1] = t[F_M11 * pl + idx];
+    a.v[0 * 4 + 0] = t(F_M00, j);
+    a.v[1 * 4 + 0] = t(F_M01, j);
+    a.v[1 * 4 + 1] = t(F_M11, j);
     a.v[0 * 4 + 1] = m10 + dc1 * ut.f2;
   } else {
     FreqTerms ft = ut;
-    if constexpr (!UNIFORM) ft = freq_terms<false>(f, t[F_ROTM * pl + idx], s.lambda);
+    if constexpr (!UNIFORM) ft = freq_terms<false>(f, t(F_ROTM, j), lambda);
     const double dl = a.v[2 * 4 + 3];
     const double q = dl * ft.rel_rot;
-    const double x = t[F_DL2 * pl + idx] / (ft.w_rsq * dc1);
-    a.v[0 * 4 + 0] = t[F_M00 * pl + idx] - q;  // += (-dl)*rel_rot
-    a.v[1 * 4 + 0] = t[F_M01 * pl + idx] + x;
+    const double x = t(F_DL2, j) / (ft.w_rsq * dc1);
+    a.v[0 * 4 + 0] = t(F_M00, j) - q;  // += (-dl)*rel_rot
+    a.v[1 * 4 + 0] = t(F_M01, j) + x;
     a.v[2 * 4 + 0] = 0.0 + x;
-    a.v[1 * 4 + 1] = t[F_M11 * pl + idx] + q;
+    a.v[1 * 4 + 1] = t(F_M11, j) + q;
     a.v[2 * 4 + 1] = 0.0 + q;
     a.v[0 * 4 + 1] = m10 + dc1 * ft.fr2 * ft.w;
   }

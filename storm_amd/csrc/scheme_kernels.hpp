@@ -19,13 +19,19 @@
 namespace STORM_NS {
 using namespace storm;
 
-template <int SCHEME, bool ELL0, bool UNIFORM>
-SDEV M4 interval_step(const SystemDev& s, size_t i, double f, const FreqTerms& ut, bool& ok) {
+template <int SCHEME, bool ELL0, bool UNIFORM, class Coef>
+SDEV M4 interval_step_from(const Coef& c, double lambda, double f, const FreqTerms& ut, bool& ok) {
   constexpr int P = scheme_points(SCHEME);
   M4 a[P];
 #pragma unroll
-  for (int j = 0; j < P; ++j) a[j] = point_matrix<ELL0, UNIFORM>(s, (size_t)j * s.n_int + i, f, ut);
+  for (int j = 0; j < P; ++j) a[j] = point_matrix<ELL0, UNIFORM>(c, j, lambda, f, ut);
   return step_matrix<SCHEME>(a, ok);
+}
+
+template <int SCHEME, bool ELL0, bool UNIFORM>
+SDEV M4 interval_step(const SystemDev& s, size_t i, double f, const FreqTerms& ut, bool& ok) {
+  const GlobalCoef c{s.tab + i, s.plane, s.stride};
+  return interval_step_from<SCHEME, ELL0, UNIFORM>(c, s.lambda, f, ut, ok);
 }
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
@@ -114,15 +120,16 @@ __global__ __launch_bounds__(64) void det_quad_kernel(SystemDev s, const double*
   }
 }
 
-// 16 lanes per frequency ("hex" kernel, 4 frequencies per wave).  Round t: lane s of a group builds
-// the step matrix of interval 16t+s (phase A), parks it row-major in LDS, then the group multiplies
-// the 16 matrices into the running product in interval order (phase B): lane (r, c) owns element
-// (r, c) of the product, reads row r of each step matrix from LDS and gets column c of the product
-// from its quad by DPP.  Element by element this is the reference's gemm (same order as the
-// ordered-product kernel in common_kernels.hip), so results stay bit-identical while one launch
-// exposes n/4 waves.
-constexpr int kHexLaneStride = 18;                       // doubles; 16 + 2 of padding (LDS banks)
-constexpr int kHexGroupStride = 16 * kHexLaneStride + 4;  // doubles
+// LPF (16 or 32) lanes per frequency ("hex" kernel, 64/LPF frequencies per wave).  Round t: lane s of a
+// group builds the step matrix of interval LPF*t+s (phase A), parks it row-major in LDS, then the group
+// multiplies the LPF matrices into the running product in interval order (phase B): lane (r, c) owns
+// element (r, c) of the product, reads row r of each step matrix from LDS and gets column c of the
+// product from its quad by DPP (with LPF = 32 the two 16-lane halves of a group carry the same product).
+// Element by element this is the reference's gemm (same order as the ordered-product kernel in
+// common_kernels.hip), so results stay bit-identical while one launch exposes n*LPF/64 waves: the host
+// picks the LPF whose wave count packs the chip's wave slots best (see launch_hex in scheme_tu.hip).
+constexpr int kHexLaneStride = 18;  // doubles; 16 + 2 of padding (LDS banks)
+__host__ __device__ constexpr int hex_group_stride(int lpf) { return lpf * kHexLaneStride + 4; }  // doubles
 
 SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
   const double a0 = quad_bcast_d<0>(acc), a1 = quad_bcast_d<1>(acc), a2 = quad_bcast_d<2>(acc), a3 = quad_bcast_d<3>(acc);
@@ -139,26 +146,79 @@ __host__ __device__ constexpr int hex_min_waves(int scheme) {
   return (scheme == kMagnus2 || scheme == kMagnus4 || scheme == kMagnus6) ? 2 : 1;
 }
 
-template <int SCHEME, bool ELL0, bool UNIFORM>
+// Coefficient staging for det_hex: the 13*P plane rows of the NEXT round (LPF intervals per row) are
+// copied global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPRs) while
+// the current round computes, so a wave that is alone on its SIMD does not wait for L2 at the top of a
+// round. Measured A/B on the box (LPF 16, n = 10^4, tams): Colloc8 +5.5 %, Colloc6 +2 %, Colloc4 -1.6 %,
+// Magnus4 -10 %, Magnus6 0 %, Magnus8 -3 %  ->  enabled where it pays (and where two tiles per wave
+// leave the LDS room for the kernel's occupancy: Colloc6 runs two waves per SIMD).
+__host__ __device__ constexpr bool hex_prefetch(int scheme, int lpf) {
+  return scheme == kColloc8 || (scheme == kColloc6 && lpf == 16);
+}
+__host__ __device__ constexpr int hex_rows_per_dma(int lpf) { return 128 / lpf; }  // 1 KB / (lpf * 8 B)
+__host__ __device__ constexpr int hex_coef_rows(int scheme, int lpf) {
+  return (kNumFields * scheme_points(scheme) + hex_rows_per_dma(lpf) - 1) / hex_rows_per_dma(lpf) * hex_rows_per_dma(lpf);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
+
+template <int SCHEME, int LPF>
+SDEV void hex_stage_coefficients(const SystemDev& s, size_t i0, double* tile, int lane) {
+  constexpr int kRows = kNumFields * scheme_points(SCHEME);
+  constexpr int kRpd = hex_rows_per_dma(LPF);
+  constexpr int kPieces = LPF / 2;  // 16-byte pieces per row
+#pragma unroll
+  for (int q = 0; q < hex_coef_rows(SCHEME, LPF) / kRpd; ++q) {
+    int row = q * kRpd + lane / kPieces;
+    row = row < kRows ? row : kRows - 1;  // surplus lanes re-read the last row into the tile's slack rows
+    const double* src = s.tab + (size_t)row * s.stride + i0 + (lane % kPieces) * 2;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 128), 16, 0, 0);
+  }
+}
+
+template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
 __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                      double* __restrict__ det_out, int* __restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) double lds[4 * kHexGroupStride];
+  static_assert(LPF == 16 || LPF == 32 || LPF == 64, "lanes per frequency");
+  constexpr int kFreqs = 64 / LPF;  // frequencies per wave
+  constexpr int kGroup = hex_group_stride(LPF);
+  constexpr bool kPrefetch = hex_prefetch(SCHEME, LPF);
+  constexpr int kTile = kPrefetch ? hex_coef_rows(SCHEME, LPF) * LPF : 2;  // doubles per coefficient tile
+  __shared__ __attribute__((aligned(16))) double lds[kFreqs * kGroup];
+  __shared__ __attribute__((aligned(16))) double coef[2 * kTile];
   const int tid = threadIdx.x;
-  const int g = tid >> 4;    // frequency within the wave
-  const int sub = tid & 15;  // interval within the round (phase A) / element c*4+r (phase B)
-  const int r = sub & 3;
-  const int c = sub >> 2;
-  const size_t t = (size_t)blockIdx.x * 4 + g;
+  const int g = tid / LPF;    // frequency within the wave
+  const int sub = tid % LPF;  // interval within the round (phase A)
+  const int e = tid & 15;     // element c*4+r of the product (phase B)
+  const int r = e & 3;
+  const int c = e >> 2;
+  const size_t t = (size_t)blockIdx.x * kFreqs + g;
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
   double acc = (r == c) ? 1.0 : 0.0;
   const size_t n_int = s.n_int;
-  double* __restrict__ mine = lds + g * kHexGroupStride + sub * kHexLaneStride;
-  const double* __restrict__ rows = lds + g * kHexGroupStride + r * 4;
-  for (size_t i0 = 0; i0 < n_int; i0 += 16) {
-    const size_t i = i0 + sub;
-    const M4 l = interval_step<SCHEME, ELL0, UNIFORM>(s, i < n_int ? i : n_int - 1, f, ut, ok);
+  double* __restrict__ mine = lds + g * kGroup + sub * kHexLaneStride;
+  const double* __restrict__ rows = lds + g * kGroup + r * 4;
+  if constexpr (kPrefetch) {
+    if (n_int > 0) hex_stage_coefficients<SCHEME, LPF>(s, 0, coef, tid);
+  }
+  int buf = 0;
+  for (size_t i0 = 0; i0 < n_int; i0 += LPF) {
+    M4 l;
+    if constexpr (kPrefetch) {
+      // tile `buf` was requested one round ago (or in the prologue): make sure it has landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (i0 + LPF < n_int) hex_stage_coefficients<SCHEME, LPF>(s, i0 + LPF, coef + (buf ^ 1) * kTile, tid);
+      const LdsCoef<scheme_points(SCHEME), LPF> cf{coef + buf * kTile + sub};
+      l = interval_step_from<SCHEME, ELL0, UNIFORM>(cf, s.lambda, f, ut, ok);
+      buf ^= 1;
+    } else {
+      // rows are padded past n_int with copies of the last interval, so no clamping is needed
+      l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + sub, f, ut, ok);
+    }
     __syncthreads();  // previous round's rows have been consumed
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {  // row-major: row rr = {L(rr,0..3)}
@@ -166,30 +226,34 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
       *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
     }
     __syncthreads();
-    double2 lo[16], hi[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      lo[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride);
-      hi[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride + 2);
-    }
-    if (i0 + 16 <= n_int) {
+    for (int h = 0; h < LPF; h += 16) {
+      double2 lo[16], hi[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc = hex_chain_step(acc, lo[k], hi[k]);
-    } else {
+      for (int k = 0; k < 16; ++k) {
+        lo[k] = *reinterpret_cast<const double2*>(rows + (h + k) * kHexLaneStride);
+        hi[k] = *reinterpret_cast<const double2*>(rows + (h + k) * kHexLaneStride + 2);
+      }
+      if (i0 + h + 16 <= n_int) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (i0 + k < n_int) acc = hex_chain_step(acc, lo[k], hi[k]);
+        for (int k = 0; k < 16; ++k) acc = hex_chain_step(acc, lo[k], hi[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (i0 + h + k < n_int) acc = hex_chain_step(acc, lo[k], hi[k]);
+      }
     }
   }
   __syncthreads();
-  lds[g * kHexGroupStride + sub] = acc;  // column-major element c*4+r
+  if (sub < 16) lds[g * kGroup + e] = acc;  // column-major element c*4+r
   const unsigned long long bad = __ballot(!ok);
   __syncthreads();
   if (sub == 0 && t < n) {
     M4 a;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a.v[e] = lds[g * kHexGroupStride + e];
-    const bool group_ok = ((bad >> (tid & 48)) & 0xffffULL) == 0;
+    for (int k = 0; k < 16; ++k) a.v[k] = lds[g * kGroup + k];
+    constexpr unsigned long long kMask = LPF == 64 ? ~0ULL : ((1ULL << (LPF & 63)) - 1ULL);
+    const bool group_ok = ((bad >> (g * LPF)) & kMask) == 0;
     const double det = close_determinant<ELL0>(s, f, a);
     det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
     if (!group_ok) atomicOr(flags, 1);

@@ -24,11 +24,39 @@ static hipError_t launch_quad_v(const LaunchArgs& a) {
   det_quad_kernel<STORM_SCHEME, ELL0, UNIFORM><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
   return hipGetLastError();
 }
+// Waves of det_hex all run for the same time, so a launch takes ceil(waves / slots) "wave rounds".
+// LPF lanes per frequency gives n*LPF/64 waves of n_int/LPF rounds, each costing the step matrix
+// (F_scheme instructions) plus LPF ordered-product steps (7 flops + DPP moves + LDS reads, weighed as 20
+// instructions: calibrated on the box, scripts/kernel_bench.py --lanes): pick the cheaper packing.
+template <bool ELL0, bool UNIFORM, int LPF>
+static size_t hex_wave_slots() {
+  static const size_t slots = [] {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF>, 64, 0) != hipSuccess)
+      return size_t(1024);
+    return size_t(cus > 0 ? cus : 256) * size_t(per_cu > 0 ? per_cu : 4);
+  }();
+  return slots;
+}
+template <bool ELL0, bool UNIFORM, int LPF>
+static double hex_cost(size_t n, size_t n_int) {
+  constexpr double kStepFlops[8] = {610., 1396., 2694., 5048., 1486., 1848., 2562., 3900.};
+  const size_t waves = (n * LPF + 63) / 64, slots = hex_wave_slots<ELL0, UNIFORM, LPF>();
+  return double((waves + slots - 1) / slots) * double((n_int + LPF - 1) / LPF) * (kStepFlops[STORM_SCHEME] + 20.0 * LPF);
+}
+template <bool ELL0, bool UNIFORM, int LPF>
+static hipError_t launch_hex_lpf(const LaunchArgs& a) {
+  const unsigned blocks = (unsigned)((a.n * LPF + 63) / 64);
+  det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
+  return hipGetLastError();
+}
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_hex_v(const LaunchArgs& a) {
-  const unsigned blocks = (unsigned)((a.n + 3) / 4);
-  det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
-  return hipGetLastError();
+  int lpf = a.hex_lanes;
+  if (lpf != 16 && lpf != 32)
+    lpf = hex_cost<ELL0, UNIFORM, 32>(a.n, a.sys.n_int) < hex_cost<ELL0, UNIFORM, 16>(a.n, a.sys.n_int) ? 32 : 16;
+  return lpf == 32 ? launch_hex_lpf<ELL0, UNIFORM, 32>(a) : launch_hex_lpf<ELL0, UNIFORM, 16>(a);
 }
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_build_v(const LaunchArgs& a) {

@@ -104,7 +104,8 @@ struct storm_solver {
   size_t fused_min_n = size_t(1) << 62;          // auto: lane-per-frequency kernel from this batch size on (off: the
                                                  // 16-lane kernel is faster at every size measured)
   size_t quad_min_n = size_t(1) << 62;           // auto: quad kernel from this batch size on (off by default)
-  size_t hex_min_n = 512;                        // auto: 16-lanes-per-frequency kernel from this batch size on
+  size_t hex_min_n = 512;                        // auto: 16/32-lanes-per-frequency kernel from this batch size on
+  int hex_lanes = 0;                             // lanes per frequency of that kernel: 0 = by wave-slot packing, 16, 32
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
   bool profile = false;
@@ -149,18 +150,20 @@ int guarded(F&& f) {
 // Frequency-independent planes: Rotating1D::eval (reference src/system/adiabatic.rs:78-114) per
 // collocation point, plus dx*c1, (dx*lambda)^2 and m*rot for add_frequency (:116-152).
 // Host arithmetic here is un-fused (this file is built with -ffp-contract=off).
+size_t padded_stride(size_t n_int) { return (n_int + 63) / 64 * 64 + 64; }
+
 void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& uniform, double& rotm0) {
-  const size_t n_int = d.n_int, p = d.p, plane = n_int * p;
+  const size_t n_int = d.n_int, p = d.p, stride = padded_stride(n_int), plane = stride * p;
   tab.assign(plane * kNumFields, 0.0);
   const double ell = double(d.ell), mm = double(d.m);
   const double lambda = ell * (ell + 1.0);
   uniform = true;
-  rotm0 = plane ? mm * d.rot[0] : 0.0;
+  rotm0 = n_int ? mm * d.rot[0] : 0.0;
   uint64_t rot_bits0;
   std::memcpy(&rot_bits0, &rotm0, 8);
   for (size_t i = 0; i < n_int; ++i)
     for (size_t j = 0; j < p; ++j) {
-      const size_t src = i * p + j, dst = j * n_int + i;
+      const size_t src = i * p + j, dst = j * stride + i;
       const double dx = d.delta_over_x[src], u = d.u[src], vg = d.v_gamma[src], as = d.a_star[src];
       double* t = tab.data();
       t[F_M00 * plane + dst] = dx * (vg - 1.0 - ell);
@@ -182,6 +185,13 @@ void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& un
       std::memcpy(&b, &rotm, 8);
       if (b != rot_bits0) uniform = false;
     }
+  // padding: repeat the last interval (kernels may evaluate, but never apply, up to 31 intervals past the end)
+  if (n_int)
+    for (size_t fld = 0; fld < size_t(kNumFields); ++fld)
+      for (size_t j = 0; j < p; ++j) {
+        double* row = tab.data() + fld * plane + j * stride;
+        for (size_t i = n_int; i < stride; ++i) row[i] = row[n_int - 1];
+      }
 }
 
 void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
@@ -235,7 +245,7 @@ void check_flags(storm_solver* s) {
 LaunchArgs make_args(storm_solver* s, const double* d_freq, size_t n, double* out, hipStream_t st) {
   LaunchArgs a;
   a.sys = s->sys; a.freq = d_freq; a.n = n; a.out = out; a.flags = s->d_flags.p;
-  a.ell0 = s->ell0; a.uniform = s->uniform; a.stream = st;
+  a.ell0 = s->ell0; a.uniform = s->uniform; a.hex_lanes = s->hex_lanes; a.stream = st;
   return a;
 }
 
@@ -426,7 +436,8 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags memset");
     hip_check(hipStreamSynchronize(s->stream), "create sync");
     s->sys.tab = s->tab.p;
-    s->sys.plane = d->n_int * d->p;
+    s->sys.stride = padded_stride(d->n_int);
+    s->sys.plane = s->sys.stride * d->p;
     s->sys.n_int = d->n_int;
     s->sys.ell = ell;
     s->sys.lambda = ell * (ell + 1.0);
@@ -478,6 +489,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     } else if (k == "hex_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
       s->hex_min_n = size_t(value);
+    } else if (k == "hex_lanes") {
+      if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
+      s->hex_lanes = int(value);
     } else if (k == "quad_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "quad_min_n must be >= 0");
       s->quad_min_n = size_t(value);

@@ -30,7 +30,10 @@ enum Field : int {
 
 struct SystemDev {
   const double* tab;   // kNumFields planes
-  size_t plane;        // doubles per plane (= p * n_int)
+  size_t plane;        // doubles per plane (= p * stride)
+  size_t stride;       // doubles per (field, point) row: n_int rounded up to 16, plus 16 (rows are 128-B
+                       // aligned and may be read one 16-interval round past the end; the padding repeats
+                       // the last interval)
   size_t n_int;        // grid intervals
   double ell, lambda;  // lambda = ell*(ell+1)
   double inner_c1, inner_rotm, outer_u;
@@ -44,6 +47,7 @@ struct LaunchArgs {
   double* out;         // det_out (fused kernels) or steps (build), device
   int* flags;          // device
   bool ell0, uniform;
+  int hex_lanes;       // det_hex only: lanes per frequency, 16 or 32; 0 = pick by wave-slot packing
   hipStream_t stream;
 };
 typedef hipError_t (*launch_fn)(const LaunchArgs&);

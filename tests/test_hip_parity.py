@@ -87,6 +87,17 @@ def test_mode_id(host, host_models, known_answers, name):
 # ---------------------------------------------------------------------------------------------
 # kernel parity against the oracle on identical inputs
 # ---------------------------------------------------------------------------------------------
+def each_det_path(h):
+    """Forces every discriminant kernel in turn (all must give the same bits): fused, split, quad,
+    hex with 16 and with 32 lanes per frequency; restores the automatic choice afterwards."""
+    for path, lanes in ((1, 0), (2, 0), (3, 0), (4, 16), (4, 32)):
+        h.set_option("path", path)
+        h.set_option("hex_lanes", lanes)
+        yield f"path {path} lanes {lanes}"
+    h.set_option("path", 0)
+    h.set_option("hex_lanes", 0)
+
+
 @pytest.mark.parametrize("ell", [0, 1, 2])
 @pytest.mark.parametrize("scheme", SCHEMES)
 def test_det_bit_exact_both_paths(oracle, oracle_models, scheme, ell):
@@ -95,8 +106,7 @@ def test_det_bit_exact_both_paths(oracle, oracle_models, scheme, ell):
     h = hip_from_oracle(o)
     freqs = np.concatenate([oracle.linspace(0.7, 30.0, 61), [3.3047719, 10.0, 24.999]])
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3, 4):
-        h.set_option("path", path)
+    for path in each_det_path(h):
         got = h.det(freqs)
         assert same_bits(ref, got), f"path {path}"
 
@@ -112,8 +122,7 @@ def test_det_uniform_rotation(oracle, golden_dir, scheme, ell, m):
     h = hip_from_oracle(o)
     freqs = oracle.linspace(1.0, 25.0, 40)
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3, 4):
-        h.set_option("path", path)
+    for path in each_det_path(h):
         assert same_bits(ref, h.det(freqs)), f"path {path}"
 
 
@@ -127,8 +136,7 @@ def test_det_differential_rotation(oracle, golden_dir, scheme):
     h = hip_from_oracle(o)
     freqs = oracle.linspace(1.0, 20.0, 33)
     ref = o.det(freqs, threads=16)
-    for path in (1, 2, 3, 4):
-        h.set_option("path", path)
+    for path in each_det_path(h):
         assert same_bits(ref, h.det(freqs)), f"path {path}"
 
 
@@ -195,8 +203,7 @@ def test_empty_and_tiny_batches(oracle, oracle_models):
     assert res == [] and same_bits(dets, o.det(5.0))
     for n in (1, 2, 3, 5, 63, 64, 65, 130):
         f = oracle.linspace(2.0, 9.0, n) if n > 1 else np.array([2.0])
-        for path in (1, 2, 3, 4):
-            h.set_option("path", path)
+        for path in each_det_path(h):
             assert same_bits(o.det(f, threads=16), h.det(f)), (n, path)
 
 
@@ -211,8 +218,7 @@ def test_tiny_grids(oracle, npts):
             h = hip_from_oracle(o)
             f = oracle.linspace(1.0, 6.0, 7)
             ref = o.det(f)
-            for path in (1, 2, 3, 4):
-                h.set_option("path", path)
+            for path in each_det_path(h):
                 assert same_bits(ref, h.det(f)), (scheme, ell, path)
             rdet, rvec = o.eigenvector(f[:3])
             gdet, gvec = h.eigenvector(f[:3])
@@ -283,8 +289,7 @@ def test_full_size_scan_config2(oracle, golden_dir, scheme, ell):
     ulp = oracle.relative_to_ulp(1e-8)
     gres, gdets, ginv = h.scan_and_optimize(f, ulp)
     # (1) the two kernel paths agree bit for bit on the whole grid
-    for path in (1, 2, 3, 4):
-        h.set_option("path", path)
+    for path in each_det_path(h):
         assert same_bits(gdets, h.det(f)), path
     h.set_option("path", 0)
     # (2) sampled comparison with the oracle (512 of 10^4 points) and every bracket end point
