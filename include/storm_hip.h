@@ -99,6 +99,55 @@ int storm_scan_and_optimize(storm_solver* solver, const double* freq, size_t n, 
  * vec_out is [n][(n_int+1)*4], element [i*4+k] = y_{k+1}(x_i); det_out (may be NULL) is [n]. */
 int storm_eigenvector_batch(storm_solver* solver, const double* freq, size_t n, double* det_out, double* vec_out);
 
+/* ---- Post-processing of found modes (the caller of the scan path: `post-process`, src/main.rs:878-899) ----
+ *
+ * Replaces Rotating1DPostprocessing::new (src/postprocessing.rs:58-301) and count_windings (:304-355),
+ * batched over modes and run on the device, so eigenvectors need not leave HBM to get mode ids. */
+
+/* DimensionlessProperties (src/model.rs:70-91) of the model EVALUATED ON THE SOLVER GRID, i.e. what
+ * `input.as_continuous().eval(&input.grid())` returns (src/main.rs:892).  n_pts = n_int + 1 of the solvers
+ * used with it; r_coord[0] must be 0 (assert_eq!, src/postprocessing.rs:69).  Host pointers, borrowed for
+ * the duration of storm_postproc_create only. */
+typedef struct {
+  size_t n_pts;
+  const double *r_coord, *m_coord, *rho, *p, *v, *u, *gamma1, *a_star, *c1, *rot;
+} storm_model_desc;
+
+typedef struct storm_postproc storm_postproc; /* opaque; owns the model arrays in HBM and a stream */
+
+/* Field order of fields_out; = the Box<[f64]> members of Rotating1DPostprocessing, src/postprocessing.rs:14-42
+ * (x is the caller's r_coord and is not returned). */
+typedef enum {
+  STORM_POST_Y1 = 0, STORM_POST_Y2, STORM_POST_Y3, STORM_POST_Y4, STORM_POST_XI_R, STORM_POST_XI_H,
+  STORM_POST_XI_TN, STORM_POST_XI_TP, STORM_POST_PSI, STORM_POST_DPSI, STORM_POST_RHO, STORM_POST_P,
+  STORM_POST_CHI, STORM_POST_FIELDS = 13
+} storm_post_field;
+
+/* cross_clockwise, cross_counter_clockwise, radial_order (src/postprocessing.rs:43-51) and nodes.len(). */
+typedef struct {
+  uint64_t cross_clockwise, cross_counter_clockwise;
+  int64_t radial_order;
+  uint64_t n_nodes;
+} storm_mode_id;
+
+int storm_postproc_create(const storm_model_desc* model, storm_postproc** out);
+void storm_postproc_destroy(storm_postproc* post);
+
+/* Rotating1DPostprocessing::new(freq[k], eigenvectors[k], ell, m, model) for k < n.  Host pointers:
+ * eigenvectors [n][n_pts*4] as returned by storm_eigenvector_batch; fields_out [n][STORM_POST_FIELDS][n_pts]
+ * (may be NULL: ids only); ids_out [n]; nodes_out [n][node_cap] (may be NULL) receives the first
+ * min(n_nodes, node_cap) radial node positions of each mode in ascending grid order. */
+int storm_postprocess_batch(storm_postproc* post, uint64_t ell, int64_t m, const double* freq, size_t n,
+                            const double* eigenvectors, double* fields_out, storm_mode_id* ids_out,
+                            double* nodes_out, size_t node_cap);
+
+/* The `eigenvector` closure and the post-processing fused: what StormState::scan's per-mode loop followed by
+ * `post-process` computes (src/main.rs:822-831,878-899), with the eigenvectors staying in HBM between the two.
+ * ell and m are the solver's; the solver grid must be the model grid (n_int + 1 == n_pts).  det_out, vec_out,
+ * fields_out, nodes_out may each be NULL (then nothing is copied back for them). */
+int storm_modes_batch(storm_solver* solver, storm_postproc* post, const double* freq, size_t n, double* det_out,
+                      double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap);
+
 /* Precision::Relative(p).as_ulp(), src/bracket.rs:30-40. */
 uint64_t storm_precision_relative_to_ulp(double relative_precision);
 
@@ -112,7 +161,7 @@ int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
 /* Per-kernel device time, measured with HIP events recorded on the launch stream around every
  * launch while option "profile" is 1.  ms_out / launches_out have STORM_KERNEL_KINDS entries. */
 enum { STORM_KERNEL_DET_FUSED = 0, STORM_KERNEL_BUILD_STEPS = 1, STORM_KERNEL_CHAIN = 2, STORM_KERNEL_EIGEN = 3,
-       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_DET_HEX = 5, STORM_KERNEL_KINDS = 6 };
+       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_DET_HEX = 5, STORM_KERNEL_POSTPROCESS = 6, STORM_KERNEL_KINDS = 7 };
 int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* launches_out, int reset);
 
 /* Options.  Every "path" is bit-identical; only "arithmetic" = 1 changes results (to rounding).

@@ -385,10 +385,11 @@ inline Mat<T, 4> step_matrix(int scheme, const Mat<T, 4>* v) {
 
 // ---------------------------------------------------------------------------
 // Model layer.  src/model.rs, src/model/{gsm,interpolate,polytrope}.rs
-// Only the fields the adiabatic system consumes are carried.
+// DimensionlessProperties, model.rs:70-91 (m_coord, rho, p are consumed by the post-processing only).
 // ---------------------------------------------------------------------------
 struct DiscreteModel {
   std::vector<double> r_coord, v, u, gamma1, a_star, c1, rot;
+  std::vector<double> m_coord, rho, p;
   bool has_scale = false;
   double radius = 0., mass = 0., grav = 0.;
   size_t size() const { return r_coord.size(); }
@@ -405,7 +406,9 @@ inline DiscreteModel model_from_gsm(size_t n, const double* r, const double* m_r
   md.has_scale = true; md.radius = radius; md.mass = mass; md.grav = GRAV;
   md.r_coord.resize(n); md.v.resize(n); md.u.resize(n); md.gamma1.resize(n);
   md.a_star.resize(n); md.c1.resize(n); md.rot.resize(n);
+  md.m_coord.resize(n); md.rho.resize(n); md.p.resize(n);
   const double r3 = cube(radius);
+  const double r4 = (radius * radius) * (radius * radius);          // f64::powi(4)
   const double fscale = std::sqrt(GRAV * mass / r3);
   const double fourpi = 4. * M_PI;
   for (size_t i = 0; i < n; ++i) {
@@ -416,6 +419,9 @@ inline DiscreteModel model_from_gsm(size_t n, const double* r, const double* m_r
     md.u[i] = fourpi * rho[i] * cube(r[i]) / m_r[i];            // gsm.rs:89
     md.r_coord[i] = r[i] / radius;                              // gsm.rs:94
     md.gamma1[i] = gamma1[i];
+    md.m_coord[i] = m_r[i] / mass;                              // gsm.rs:95
+    md.rho[i] = rho[i] / mass * r3;                             // gsm.rs:96
+    md.p[i] = p[i] / GRAV / (mass * mass) * r4;                 // gsm.rs:97
   }
   md.c1[0] = mass / r3 * 3. / (fourpi * rho[0]);                // gsm.rs:84
   md.a_star[0] = 0.; md.v[0] = 0.; md.u[0] = 3.;                // gsm.rs:86,88,90
@@ -429,6 +435,7 @@ inline DiscreteModel interpolate_eval(const DiscreteModel& model, const std::vec
   const size_t ng = grid.size();
   out.r_coord.assign(ng, 0.); out.v.assign(ng, 0.); out.u.assign(ng, 0.); out.gamma1.assign(ng, 0.);
   out.a_star.assign(ng, 0.); out.c1.assign(ng, 0.); out.rot.assign(ng, 0.);
+  out.m_coord.assign(ng, 0.); out.rho.assign(ng, 0.); out.p.assign(ng, 0.);
   if (ng == 0) throw std::runtime_error("empty grid");
   const std::vector<double>& x = model.r_coord;
   size_t old_it = 0;           // next index the old-grid iterator will yield
@@ -439,6 +446,7 @@ inline DiscreteModel interpolate_eval(const DiscreteModel& model, const std::vec
       out.r_coord[cur] = model.r_coord[next]; out.v[cur] = model.v[next]; out.u[cur] = model.u[next];
       out.gamma1[cur] = model.gamma1[next]; out.a_star[cur] = model.a_star[next];
       out.c1[cur] = model.c1[next]; out.rot[cur] = model.rot[next];
+      out.m_coord[cur] = model.m_coord[next]; out.rho[cur] = model.rho[next]; out.p[cur] = model.p[next];
       if (++cur < ng) continue; else break;
     } else if (x[next] > grid[cur]) {
       double pos = (grid[cur] - x[prev]) / (x[next] - x[prev]);
@@ -446,6 +454,7 @@ inline DiscreteModel interpolate_eval(const DiscreteModel& model, const std::vec
 #define STORM_REF_INTERP(f) out.f[cur] = model.f[prev] + pos * (model.f[next] - model.f[prev])
       STORM_REF_INTERP(v); STORM_REF_INTERP(u); STORM_REF_INTERP(gamma1);
       STORM_REF_INTERP(a_star); STORM_REF_INTERP(c1); STORM_REF_INTERP(rot);
+      STORM_REF_INTERP(m_coord); STORM_REF_INTERP(rho); STORM_REF_INTERP(p);
 #undef STORM_REF_INTERP
       if (++cur < ng) continue; else break;
     }
@@ -463,10 +472,14 @@ inline DiscreteModel polytrope0_eval(double gamma1, const std::vector<double>& g
   out.r_coord = grid;
   out.v.resize(n); out.a_star.resize(n);
   out.u.assign(n, 3.); out.gamma1.assign(n, gamma1); out.c1.assign(n, 1.); out.rot.assign(n, 0.);
+  out.rho.assign(n, 3. / (4. * M_PI)); out.m_coord.resize(n);               // polytrope.rs:223-225
+  out.p.assign(n, std::numeric_limits<double>::infinity());
+  const double phi_max = cube(POLY0_MAX_X) / 3.;
   for (size_t i = 0; i < n; ++i) {
     double xi = grid[i] * POLY0_MAX_X;
     double theta = 1. - xi * xi / 6.;
     double phi = cube(xi) / 3.;
+    out.m_coord[i] = phi / phi_max;
     out.v[i] = phi / (xi * theta);
     out.a_star[i] = -phi / (xi * theta * gamma1);
   }
@@ -589,8 +602,11 @@ inline DiscreteModel construct_polytrope(double n, double gamma1, double step) {
   DiscreteModel md;
   md.r_coord.resize(len); md.v.resize(len); md.u.resize(len); md.a_star.resize(len); md.c1.resize(len);
   md.gamma1.assign(len, gamma1); md.rot.assign(len, 0.);
+  md.m_coord.resize(len); md.rho.resize(len); md.p.resize(len);
   for (size_t i = 0; i < len; ++i) {
     double xi = xis[i], th = thetas[i], ph = phis[i];
+    md.m_coord[i] = ph / max_phi;                                    // :139
+    md.rho[i] = std::pow(th, n) * cube(max_xi) / (max_phi * 4. * M_PI);  // :143
     md.u[i] = cube(xi) * std::pow(th, n) / ph;                       // polytrope.rs:107
     md.v[i] = (n + 1.) * ph / (xi * th);                             // :116
     md.c1[i] = cube(xi) / cube(max_xi) * max_phi / ph;               // :124
@@ -598,6 +614,8 @@ inline DiscreteModel construct_polytrope(double n, double gamma1, double step) {
     md.r_coord[i] = xi / max_xi;                                     // :138
   }
   md.u[0] = 3.; md.v[0] = 0.; md.c1[0] = max_phi / cube(max_xi) * 3.; md.a_star[0] = 0.;
+  const double kk = 4. * M_PI / (std::pow(md.rho[0], 1. / n - 1.) * (n + 1.) * (max_xi * max_xi));  // :146
+  for (size_t i = 0; i < len; ++i) md.p[i] = std::pow(md.rho[i], 1. + 1. / n) * kk;                  // :147
   return md;
 }
 
@@ -983,5 +1001,188 @@ struct ErasedSolver {
     return res;
   }
 };
+
+// ---------------------------------------------------------------------------
+// Post-processing.  src/postprocessing.rs, src/gaunt.rs
+// Pinned by the reference only through the mode ids (postprocessing.rs:424-498); the floating-point
+// fields are asserted nowhere in the reference: "parity unpinned" (GPU == this restatement).
+// ---------------------------------------------------------------------------
+// f64::powi with a run-time exponent = compiler-builtins' __powidf2 (square-and-multiply on |b|,
+// reciprocal at the end for b < 0); constant small exponents are spelled out as products instead.
+inline double powi(double a, int b) {
+  unsigned pw = b < 0 ? 0u - unsigned(b) : unsigned(b);
+  double mul = 1.;
+  for (;;) {
+    if (pw & 1u) mul *= a;
+    pw >>= 1;
+    if (pw == 0) break;
+    a *= a;
+  }
+  return b < 0 ? 1. / mul : mul;
+}
+inline double beta_k(uint64_t k, int64_t m) {  // gaunt.rs:1-6
+  double kf = double(k), mf = double(m);
+  return std::sqrt((kf * kf - mf * mf) / (4. * kf * kf - 1.));
+}
+inline double q_kl1(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:8-17; m % 2 truncates towards zero
+  double sign = powi(-1.0, int(m % 2));
+  return sign * (k == l + 1 ? beta_k(k, m) : (l == k + 1 ? beta_k(l, m) : 0.));
+}
+inline double q_kl1_h(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:32-37
+  double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return q_kl1(k, l, m) * ((lk + ll) / 2. - 1.);
+}
+inline double q_kl1_hd(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:46-51
+  double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return q_kl1(k, l, m) * ((ll - lk) / 2. + 1.);
+}
+
+struct Windings { uint64_t clockwise = 0, counter_clockwise = 0; std::vector<double> nodes; };
+// count_windings, postprocessing.rs:304-355 (n = number of points of the three slices).
+inline Windings count_windings(const double* y1, const double* y2, const double* x, size_t n) {
+  Windings w;
+  for (size_t i = 0; i + 1 < n; ++i) {
+    const double y1_1 = y1[i], y1_2 = y1[i + 1], y2_1 = y2[i], y2_2 = y2[i + 1], x_1 = x[i], x_2 = x[i + 1];
+    if (y1_1 <= 0. && y1_2 > 0.) {
+      double yt = y2_1 - y1_1 * (y2_2 - y2_1) / (y1_2 - y1_1);
+      double xt = x_2 - y1_1 * (x_2 - x_1) / (y1_2 - y1_1);
+      if (yt > 0.) w.clockwise += 1; else w.counter_clockwise += 1;
+      w.nodes.push_back(xt);
+    } else if (y1_1 >= 0. && y1_2 < 0.) {
+      double yt = y2_1 - y1_1 * (y2_2 - y2_1) / (y1_2 - y1_1);
+      double xt = x_2 - y1_1 * (x_2 - x_1) / (y1_2 - y1_1);
+      if (yt > 0.) w.counter_clockwise += 1; else w.clockwise += 1;
+      w.nodes.push_back(xt);
+    }
+  }
+  return w;
+}
+
+// Field order of the flat output (also the HIP library's): include/storm_hip.h storm_post_field.
+enum PostField { PF_Y1, PF_Y2, PF_Y3, PF_Y4, PF_XI_R, PF_XI_H, PF_XI_TN, PF_XI_TP, PF_PSI, PF_DPSI, PF_RHO, PF_P, PF_CHI, PF_COUNT };
+
+struct Postprocessing {  // Rotating1DPostprocessing, postprocessing.rs:14-54
+  std::vector<double> f[PF_COUNT];
+  uint64_t cross_clockwise = 0, cross_counter_clockwise = 0;
+  int64_t radial_order = 0;
+  std::vector<double> nodes;
+};
+
+// Rotating1DPostprocessing::new, postprocessing.rs:58-301.
+inline Postprocessing postprocess(double freq, const double* eigenvector, size_t eig_len, uint64_t ell, int64_t m,
+                                  const DiscreteModel& model) {
+  const size_t np = model.r_coord.size();
+  if (eig_len % 4 != 0) throw std::runtime_error("eigenvector length is not a multiple of 4");
+  if (np < 2 || eig_len != np * 4) throw std::runtime_error("eigenvector does not live on the model grid");
+  if (model.r_coord[0] != 0.) throw std::runtime_error("model.r_coord[0] must be 0");
+  Postprocessing out;
+  for (auto& v : out.f) v.assign(np, 0.);
+  std::vector<double>&y1 = out.f[PF_Y1], &y2 = out.f[PF_Y2], &y3 = out.f[PF_Y3], &y4 = out.f[PF_Y4], &xi_r = out.f[PF_XI_R],
+      &xi_h = out.f[PF_XI_H], &xi_tn = out.f[PF_XI_TN], &xi_tp = out.f[PF_XI_TP], &psi_prime = out.f[PF_PSI],
+      &dpsi_prime = out.f[PF_DPSI], &rho_prime = out.f[PF_RHO], &p_prime = out.f[PF_P], &chi = out.f[PF_CHI];
+  const double lambda = double(ell * (ell + 1));
+  const uint64_t ell_n1 = ell == 0 ? 0 : ell - 1;  // saturating_sub
+  const double lambda_n1 = double(ell * ell_n1);
+  const double lambda_p1 = double((ell + 2) * (ell + 1));
+  const double q_hd_n = q_kl1_hd(ell, ell_n1, m), q_hd_p = q_kl1_hd(ell, ell + 1, m);
+  const double q_h_n = q_kl1_h(ell, ell_n1, m), q_h_p = q_kl1_h(ell, ell + 1, m);
+  const double mf = double(m);
+  const int ell_i = int(ell);
+  const double ellf = double(ell);
+  const uint64_t m_abs = m < 0 ? uint64_t(0) - uint64_t(m) : uint64_t(m);
+  const std::vector<double>& r = model.r_coord;
+  double norm = 0.;
+  std::vector<double> trapezoid(np, 0.);  // :99-111
+  trapezoid[0] = 0.5 * (r[1] - r[0]);
+  trapezoid[np - 1] = 0.5 * (r[np - 1] - r[np - 2]);
+  for (size_t i = 1; i + 1 < np; ++i) trapezoid[i] = 0.5 * (r[i + 1] - r[i - 1]);
+
+  for (size_t i = 1; i < np; ++i) {  // :113-171
+    y1[i] = eigenvector[i * 4]; y2[i] = eigenvector[i * 4 + 1]; y3[i] = eigenvector[i * 4 + 2]; y4[i] = eigenvector[i * 4 + 3];
+    const double dphi = model.m_coord[i] / (r[i] * r[i]);
+    xi_r[i] = y1[i] * powi(r[i], ell_i - 1);
+    p_prime[i] = y2[i] * model.rho[i] * dphi * powi(r[i], ell_i - 1);
+    psi_prime[i] = y3[i] * dphi * powi(r[i], ell_i - 1);
+    dpsi_prime[i] = y4[i] * dphi * powi(r[i], ell_i - 2);
+    const double rsigma = freq - mf * model.rot[i];
+    double omega_rsq, rel_rot;
+    if (ell != 0) {
+      const double rot = mf * model.rot[i];
+      omega_rsq = (lambda * (freq - rot) + 2. * rot) * (freq - rot);
+      rel_rot = 2. * rot / (lambda * (freq - rot) + 2. * rot);
+      const double f = 2. * rot / lambda;
+      xi_h[i] = 1. / (rsigma * model.rho[i] * (rsigma + f)) *
+                ((p_prime[i] + model.rho[i] * psi_prime[i]) / r[i] - f * rsigma * model.rho[i] * xi_r[i]);
+    } else {
+      omega_rsq = 1.; rel_rot = 0.; xi_h[i] = 0.;
+    }
+    const double xdy1 = (model.v[i] / model.gamma1[i] - 1. - ellf - lambda * rel_rot) * y1[i] +
+                        (-model.v[i] / model.gamma1[i] + (lambda * lambda) / (omega_rsq * model.c1[i])) * y2[i] +
+                        (lambda * lambda) / (omega_rsq * model.c1[i]) * y3[i];
+    chi[i] = powi(r[i], ell_i - 2) * ((ellf + 1.) * y1[i] + xdy1) - lambda / r[i] * xi_h[i];
+    rho_prime[i] = -model.rho[i] * chi[i] + xi_r[i] * model.rho[i] / r[i] * (model.v[i] / model.gamma1[i] + model.a_star[i]);
+    if (m_abs == ell || ell == 1) xi_tn[i] = 0.;
+    else
+      xi_tn[i] = 2. * model.rot[i] / (lambda_n1 * (freq - mf * model.rot[i]) + 2. * mf * model.rot[i]) *
+                 (-q_hd_n * xi_r[i] + q_h_n * xi_h[i]);
+    xi_tp[i] = 2. * model.rot[i] / (lambda_p1 * (freq - mf * model.rot[i]) + 2. * mf * model.rot[i]) *
+               (-q_hd_p * xi_r[i] + q_h_p * xi_h[i]);
+    norm += model.rho[i] * (r[i] * r[i]) * (xi_r[i] * xi_r[i] + lambda * xi_h[i] * xi_h[i]) * trapezoid[i];
+  }
+  // central point, :173-224
+  y1[0] = eigenvector[0]; y2[0] = eigenvector[1]; y3[0] = eigenvector[2]; y4[0] = eigenvector[3];
+  if (ell != 1) {
+    xi_r[0] = 0.; dpsi_prime[0] = 0.; xi_h[0] = 0.;
+  } else {
+    const double ddphi0 = 4. / 3. * M_PI * model.rho[0];
+    xi_r[0] = y1[0];
+    dpsi_prime[0] = y4[0] * ddphi0;
+    const double rsigma = freq - mf * model.rot[0];
+    const double f = 2. * mf * model.rot[0] / lambda;  // ell == 1 here, so the ell != 0 arm
+    xi_h[0] = 1. / (rsigma * (rsigma + f)) * ((y2[0] + y3[0]) * ddphi0 - f * xi_r[0]);
+  }
+  if (ell == 0) {
+    p_prime[0] = y2[0] * (model.rho[0] * model.rho[0]) * 4. / 3. * M_PI;
+    psi_prime[0] = y3[0] * model.rho[0] * 4. / 3. * M_PI;
+    rho_prime[0] = model.rho[0] * p_prime[0] / (model.gamma1[0] * model.p[0]);
+    chi[0] = -rho_prime[0] / model.rho[0];
+  } else {
+    p_prime[0] = 0.; psi_prime[0] = 0.; rho_prime[0] = 0.; chi[0] = 0.;
+  }
+  if (m_abs == ell || ell == 1) xi_tn[0] = 0.;
+  else
+    xi_tn[0] = 2. * model.rot[0] / (lambda_n1 * (freq - mf * model.rot[0]) + 2. * mf * model.rot[0]) *
+               (-q_hd_n * xi_r[0] + q_h_n * xi_h[0]);
+  if (ell == 0) xi_tp[0] = 0.;
+  else
+    xi_tp[0] = 2. * model.rot[0] / (lambda_p1 * (freq - mf * model.rot[0]) + 2. * mf * model.rot[0]) *
+               (-q_hd_p * xi_r[0] + q_h_p * xi_h[0]);
+
+  const double scale = 1. / std::sqrt(norm);  // :226-242
+  for (auto& v : out.f) for (double& e : v) e *= scale;
+
+  Windings w;  // :244-279
+  if (ell == 0) {
+    w = count_windings(y1.data(), y2.data(), r.data(), np);
+    out.radial_order = int64_t(w.counter_clockwise);
+  } else if (ell == 1) {
+    std::vector<double> y1_alt(np), y2_alt(np);
+    for (size_t i = 0; i < np; ++i) {
+      y1_alt[i] = (1. - model.u[i] / 3.) * y1[i] + (y3[i] - y4[i]) / 3.;
+      y2_alt[i] = y2[i] - y1[i];
+    }
+    if (np < 2) throw std::runtime_error("grid too short");
+    w = count_windings(y1_alt.data() + 2, y2_alt.data() + 2, r.data() + 2, np - 2);
+    out.radial_order = int64_t(w.counter_clockwise) - int64_t(w.clockwise) + (w.clockwise > w.counter_clockwise ? 0 : 1);
+  } else {
+    std::vector<double> y2_alt(np);
+    for (size_t i = 0; i < np; ++i) y2_alt[i] = y2[i] + y3[i];
+    w = count_windings(y1.data(), y2_alt.data(), r.data(), np);
+    out.radial_order = int64_t(w.counter_clockwise) - int64_t(w.clockwise);
+  }
+  out.cross_clockwise = w.clockwise; out.cross_counter_clockwise = w.counter_clockwise;
+  out.nodes = std::move(w.nodes);
+  return out;
+}
 
 }  // namespace storm_ref

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libstorm_ref.so")
 
+POST_FIELDS = ["y1", "y2", "y3", "y4", "xi_r", "xi_h", "xi_tn", "xi_tp", "psi", "dpsi", "rho", "p", "chi"]
 SCHEMES = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magnus6", "magnus8"]
 
 
@@ -80,6 +81,13 @@ def lib():
         L.sref_polytrope0_exact.restype = C.c_double
         L.sref_polytrope0_exact.argtypes = [C.c_double, C.c_uint64, C.c_int64]
         L.sref_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
+        L.sref_model_eval.restype = C.c_void_p
+        L.sref_model_eval.argtypes = [C.c_void_p, _dp, C.c_size_t]
+        L.sref_postprocess_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, C.c_size_t, _dp, _dp,
+                                             C.POINTER(C.c_int64), _dp, C.c_size_t, C.POINTER(C.c_uint64), C.c_int]
+        L.sref_gaunt.argtypes = [C.c_uint64, C.c_int64, _dp]
+        L.sref_powi.restype = C.c_double
+        L.sref_powi.argtypes = [C.c_double, C.c_int]
         L.sref_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
         _lib = L
     return _lib
@@ -115,7 +123,7 @@ def relative_to_ulp(rel):
 
 
 class Model:
-    FIELDS = ["r_coord", "v", "u", "gamma1", "a_star", "c1", "rot"]
+    FIELDS = ["r_coord", "v", "u", "gamma1", "a_star", "c1", "rot", "m_coord", "rho", "p"]
 
     def __init__(self, handle, poly0=False):
         if not handle:
@@ -162,6 +170,30 @@ class Model:
         out = np.empty(n)
         lib().sref_model_grid(self._h, scale, _p(out), n)
         return out
+
+    def eval(self, grid):
+        """ContinuousModel::eval: this model on `grid` (linear interpolation, or Polytrope0's formulas)."""
+        g = _f64(grid)
+        return Model(lib().sref_model_eval(self._h, _p(g), g.size))
+
+    def postprocess(self, ell, m, freqs, vecs, threads=1, node_cap=None):
+        """Rotating1DPostprocessing::new (src/postprocessing.rs:58-301) for each (freq, eigenvector) on this
+        (already evaluated) model.  Returns dict(fields [n,13,n_pts], ids [n,3] = cw, ccw, radial order,
+        nodes = list of arrays)."""
+        f = _f64(np.atleast_1d(freqs))
+        v = _f64(vecs).reshape(f.size, -1)
+        npts = len(self)
+        assert v.shape[1] == npts * 4, "eigenvector does not live on the model grid"
+        cap = npts if node_cap is None else node_cap
+        fields = np.empty((f.size, len(POST_FIELDS), npts))
+        ids = np.empty((f.size, 3), dtype=np.int64)
+        nodes = np.full((f.size, max(cap, 1)), np.nan)
+        nn = np.zeros(f.size, dtype=np.uint64)
+        _check(lib().sref_postprocess_batch(self._h, ell, m, _p(f), f.size, _p(v), _p(fields),
+                                            ids.ctypes.data_as(C.POINTER(C.c_int64)), _p(nodes), cap,
+                                            nn.ctypes.data_as(C.POINTER(C.c_uint64)), threads))
+        return dict(fields=fields, ids=ids, n_nodes=nn.astype(np.int64),
+                    nodes=[nodes[k, :min(int(nn[k]), cap)].copy() for k in range(f.size)])
 
     def __del__(self):
         try:
@@ -270,6 +302,17 @@ def matmul4(a, b):
     out = np.empty(16)
     lib().sref_matmul4(_p(x), _p(y), _p(out))
     return out.reshape((4, 4), order="F")
+
+
+def gaunt(ell, m):
+    """{q_hd_n, q_hd_p, q_h_n, q_h_p} of src/postprocessing.rs:88-91."""
+    out = np.empty(4)
+    lib().sref_gaunt(ell, m, _p(out))
+    return out
+
+
+def powi(a, b):
+    return lib().sref_powi(a, b)
 
 
 def polytrope0_exact(gamma1, ell, radial_order):

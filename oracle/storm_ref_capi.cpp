@@ -56,11 +56,11 @@ void* sref_model_poly0(double gamma1) {
 }
 void sref_model_free(void* m) { delete static_cast<ModelHandle*>(m); }
 size_t sref_model_len(void* m) { return static_cast<ModelHandle*>(m)->discrete.size(); }
-// field: 0 r_coord, 1 v, 2 u, 3 gamma1, 4 a_star, 5 c1, 6 rot
+// field: 0 r_coord, 1 v, 2 u, 3 gamma1, 4 a_star, 5 c1, 6 rot, 7 m_coord, 8 rho, 9 p
 int sref_model_get(void* m, int field, double* out) {
   const DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
-  const std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
-  if (field < 0 || field > 6) return -1;
+  const std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot, &d.m_coord, &d.rho, &d.p};
+  if (field < 0 || field > 9) return -1;
   std::copy(f[field]->begin(), f[field]->end(), out);
   return 0;
 }
@@ -73,8 +73,8 @@ void sref_model_set_rot_const(void* m, double value) {
 // (what set-rotation-overlay does, src/model/gsm.rs:116-127, after unit conversion).
 int sref_model_set(void* m, int field, const double* in) {
   DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
-  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
-  if (field < 0 || field > 6) return -1;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot, &d.m_coord, &d.rho, &d.p};
+  if (field < 0 || field > 9) return -1;
   std::copy(in, in + f[field]->size(), f[field]->begin());
   return 0;
 }
@@ -178,6 +178,43 @@ int sref_eigenvector_batch(void* s, const double* f, size_t n, double* det_out, 
     });
   });
 }
+
+// The model evaluated on a grid (what `input.as_continuous().eval(&input.grid())` hands the post-processing,
+// src/main.rs:892): returns a new model handle holding the 10 arrays on that grid.
+void* sref_model_eval(void* m, const double* grid, size_t ngrid) {
+  ModelHandle* h = static_cast<ModelHandle*>(m);
+  ModelHandle* o = new ModelHandle();
+  if (guarded([&] { o->discrete = h->continuous().eval(std::vector<double>(grid, grid + ngrid)); })) { delete o; return nullptr; }
+  return o;
+}
+
+// Rotating1DPostprocessing::new for n modes on one (already evaluated) model.  fields_out [n][13][n_pts]
+// (order: PostField), ids_out [n][3] = {clockwise, counter-clockwise, radial order}, nodes_out [n][node_cap]
+// (may be NULL), n_nodes_out [n].
+int sref_postprocess_batch(void* m, uint64_t ell, int64_t mm, const double* freq, size_t n, const double* vec,
+                           double* fields_out, int64_t* ids_out, double* nodes_out, size_t node_cap,
+                           uint64_t* n_nodes_out, int threads) {
+  const DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
+  const size_t np = d.size();
+  return guarded([&] {
+    parallel_for(n, threads, [&](size_t k) {
+      Postprocessing pp = postprocess(freq[k], vec + k * np * 4, np * 4, ell, mm, d);
+      if (fields_out)
+        for (int f = 0; f < PF_COUNT; ++f) std::copy(pp.f[f].begin(), pp.f[f].end(), fields_out + (k * PF_COUNT + f) * np);
+      ids_out[k * 3] = int64_t(pp.cross_clockwise); ids_out[k * 3 + 1] = int64_t(pp.cross_counter_clockwise);
+      ids_out[k * 3 + 2] = pp.radial_order;
+      if (n_nodes_out) n_nodes_out[k] = pp.nodes.size();
+      if (nodes_out) std::copy(pp.nodes.begin(), pp.nodes.begin() + std::min(node_cap, pp.nodes.size()), nodes_out + k * node_cap);
+    });
+  });
+}
+int sref_gaunt(uint64_t ell, int64_t mm, double* out4) {  // {q_hd_n, q_hd_p, q_h_n, q_h_p}, postprocessing.rs:88-91
+  const uint64_t n1 = ell == 0 ? 0 : ell - 1;
+  out4[0] = q_kl1_hd(ell, n1, mm); out4[1] = q_kl1_hd(ell, ell + 1, mm);
+  out4[2] = q_kl1_h(ell, n1, mm); out4[3] = q_kl1_h(ell, ell + 1, mm);
+  return 0;
+}
+double sref_powi(double a, int b) { return powi(a, b); }
 
 // Matrix exponential known-answer entry (N = 3 or 4), column-major in place.
 int sref_exp(int n, double* a) {

@@ -54,18 +54,18 @@ void* storm_host_model_poly0(double gamma1) {
 }
 void storm_host_model_free(void* m) { delete static_cast<HostModel*>(m); }
 size_t storm_host_model_len(void* m) { return static_cast<HostModel*>(m)->discrete.len(); }
-// field: 0 r_coord, 1 v, 2 u, 3 gamma1, 4 a_star, 5 c1, 6 rot
+// field: 0 r_coord, 1 v, 2 u, 3 gamma1, 4 a_star, 5 c1, 6 rot, 7 m_coord, 8 rho, 9 p
 int storm_host_model_get(void* m, int field, double* out) {
   DimensionlessProperties& d = static_cast<HostModel*>(m)->discrete.dimensionless;
-  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
-  if (field < 0 || field > 6) return -1;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot, &d.m_coord, &d.rho, &d.p};
+  if (field < 0 || field > 9) return -1;
   std::memcpy(out, f[field]->data(), f[field]->size() * sizeof(double));
   return 0;
 }
 int storm_host_model_set(void* m, int field, const double* in) {
   DimensionlessProperties& d = static_cast<HostModel*>(m)->discrete.dimensionless;
-  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot};
-  if (field < 0 || field > 6) return -1;
+  std::vector<double>* f[] = {&d.r_coord, &d.v, &d.u, &d.gamma1, &d.a_star, &d.c1, &d.rot, &d.m_coord, &d.rho, &d.p};
+  if (field < 0 || field > 9) return -1;
   std::memcpy(f[field]->data(), in, f[field]->size() * sizeof(double));
   return 0;
 }
@@ -141,6 +141,62 @@ int storm_host_scan(void* m, const double* grid, size_t ngrid, uint64_t ell, int
       if (vec_out) std::memcpy(vec_out + k * sol[k].eigenvector.size(), sol[k].eigenvector.data(),
                                sol[k].eigenvector.size() * sizeof(double));
     }
+  });
+}
+
+// `input.as_continuous().eval(&input.grid())` (src/main.rs:892): a new model handle on `grid`.
+void* storm_host_model_eval(void* m, const double* grid, size_t ngrid) {
+  HostModel* h = static_cast<HostModel*>(m);
+  HostModel* o = new HostModel();
+  if (guarded([&] { o->discrete = h->continuous()->eval(std::vector<double>(grid, grid + ngrid)); })) { delete o; return nullptr; }
+  return o;
+}
+
+void* storm_host_postproc_new(void* m) {
+  PostProcessor* p = nullptr;
+  if (guarded([&] { p = new PostProcessor(static_cast<HostModel*>(m)->discrete); })) return nullptr;
+  return p;
+}
+void storm_host_postproc_free(void* p) { delete static_cast<PostProcessor*>(p); }
+
+namespace {
+void flatten(const std::vector<Rotating1DPostprocessing>& r, size_t np, double* fields_out, int64_t* ids_out,
+             uint64_t* n_nodes_out, double* nodes_out, size_t node_cap) {
+  for (size_t k = 0; k < r.size(); ++k) {
+    const std::vector<double>* src[STORM_POST_FIELDS] = {&r[k].y1, &r[k].y2, &r[k].y3, &r[k].y4, &r[k].xi_r, &r[k].xi_h,
+                                                         &r[k].xi_tn, &r[k].xi_tp, &r[k].psi, &r[k].dpsi, &r[k].rho,
+                                                         &r[k].p, &r[k].chi};
+    if (fields_out)
+      for (int f = 0; f < STORM_POST_FIELDS; ++f)
+        if (src[f]->size() == np) std::memcpy(fields_out + (k * STORM_POST_FIELDS + f) * np, src[f]->data(), np * sizeof(double));
+    ids_out[k * 3] = int64_t(r[k].cross_clockwise); ids_out[k * 3 + 1] = int64_t(r[k].cross_counter_clockwise);
+    ids_out[k * 3 + 2] = r[k].radial_order;
+    n_nodes_out[k] = r[k].nodes.size();
+    if (nodes_out) std::memcpy(nodes_out + k * node_cap, r[k].nodes.data(), std::min(node_cap, r[k].nodes.size()) * sizeof(double));
+  }
+}
+}  // namespace
+
+// StormState::post_process over n solutions of one (ell, m): roots [n], eigenvectors [n][n_pts*4].
+int storm_host_post_process(void* p, uint64_t ell, int64_t mm, const double* roots, const double* vecs, size_t n,
+                            double* fields_out, int64_t* ids_out, uint64_t* n_nodes_out, double* nodes_out, size_t node_cap) {
+  PostProcessor* pp = static_cast<PostProcessor*>(p);
+  return guarded([&] {
+    const size_t len = pp->len() * 4;
+    std::vector<Solution> sols(n);
+    for (size_t k = 0; k < n; ++k)
+      sols[k] = Solution{BracketResult{Point{roots[k], 0.}, Point{roots[k], 0.}, roots[k], 0},
+                         std::vector<double>(vecs + k * len, vecs + (k + 1) * len), ell, mm};
+    flatten(pp->post_process(sols), pp->len(), fields_out, ids_out, n_nodes_out, nodes_out, node_cap);
+  });
+}
+// Eigenvectors + post-processing in one device pass (PostProcessor::modes).
+int storm_host_modes(void* p, void* solver, const double* roots, size_t n, int want_fields, double* fields_out,
+                     int64_t* ids_out, uint64_t* n_nodes_out, double* nodes_out, size_t node_cap) {
+  PostProcessor* pp = static_cast<PostProcessor*>(p);
+  return guarded([&] {
+    flatten(pp->modes(*static_cast<ErasedSolver*>(solver), std::vector<double>(roots, roots + n), want_fields != 0),
+            pp->len(), want_fields ? fields_out : nullptr, ids_out, n_nodes_out, nodes_out, node_cap);
   });
 }
 

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace storm_host {
 
@@ -14,6 +15,7 @@ inline double pow3(double x) { return (x * x) * x; }  // f64::powi(3)
 void resize_all(DimensionlessProperties& d, size_t n) {
   d.r_coord.assign(n, 0.); d.v.assign(n, 0.); d.u.assign(n, 0.); d.gamma1.assign(n, 0.);
   d.a_star.assign(n, 0.); d.c1.assign(n, 0.); d.rot.assign(n, 0.);
+  d.m_coord.assign(n, 0.); d.rho.assign(n, 0.); d.p.assign(n, 0.);
 }
 
 [[noreturn]] void raise_abi(const char* what, int rc) {
@@ -34,8 +36,12 @@ DiscreteModel DiscreteModel::from_gsm_arrays(size_t n, const double* r, const do
   const double rs3 = pow3(r_star);
   const double omega_dyn = std::sqrt(kGrav * m_star / rs3);
   const double four_pi = 4. * kPi;
+  const double rs4 = (r_star * r_star) * (r_star * r_star);  // f64::powi(4)
   for (size_t k = 0; k < n; ++k) {
     const double r3 = pow3(r[k]);
+    d.m_coord[k] = m_r[k] / m_star;                      // gsm.rs:95-97
+    d.rho[k] = rho[k] / m_star * rs3;
+    d.p[k] = p[k] / kGrav / (m_star * m_star) * rs4;
     d.rot[k] = omega_rot[k] / omega_dyn;
     d.c1[k] = r3 / rs3 * m_star / m_r[k];
     d.a_star[k] = r3 / (kGrav * m_r[k]) * n2[k];
@@ -68,6 +74,7 @@ DiscreteModel LinearInterpolator::eval(const std::vector<double>& grid) const {
     if (x[hi] == want) {
       dst.r_coord[q] = x[hi]; dst.v[q] = src.v[hi]; dst.u[q] = src.u[hi]; dst.gamma1[q] = src.gamma1[hi];
       dst.a_star[q] = src.a_star[hi]; dst.c1[q] = src.c1[hi]; dst.rot[q] = src.rot[hi];
+      dst.m_coord[q] = src.m_coord[hi]; dst.rho[q] = src.rho[hi]; dst.p[q] = src.p[hi];
       if (++q == grid.size()) break;
       continue;
     }
@@ -77,6 +84,7 @@ DiscreteModel LinearInterpolator::eval(const std::vector<double>& grid) const {
       dst.r_coord[q] = want;
       dst.v[q] = lerp(src.v); dst.u[q] = lerp(src.u); dst.gamma1[q] = lerp(src.gamma1);
       dst.a_star[q] = lerp(src.a_star); dst.c1[q] = lerp(src.c1); dst.rot[q] = lerp(src.rot);
+      dst.m_coord[q] = lerp(src.m_coord); dst.rho[q] = lerp(src.rho); dst.p[q] = lerp(src.p);
       if (++q == grid.size()) break;
       continue;
     }
@@ -102,10 +110,14 @@ DiscreteModel Polytrope0::eval(const std::vector<double>& grid) const {
   DiscreteModel out;
   DimensionlessProperties& d = out.dimensionless;
   resize_all(d, grid.size());
+  const double phi_max = pow3(kPoly0MaxX) / 3.;  // polytrope.rs:221-225
   for (size_t k = 0; k < grid.size(); ++k) {
     const double xi = grid[k] * kPoly0MaxX;
     const double theta = 1. - xi * xi / 6.;
     const double phi = pow3(xi) / 3.;
+    d.rho[k] = 3. / (4. * kPi);
+    d.m_coord[k] = phi / phi_max;
+    d.p[k] = std::numeric_limits<double>::infinity();
     d.r_coord[k] = grid[k];
     d.v[k] = phi / (xi * theta);
     d.a_star[k] = -phi / (xi * theta * gamma1);
@@ -224,9 +236,13 @@ DiscreteModel construct_polytrope(double n, double gamma1, double step) {
     d.r_coord[k] = xi[k] / max_xi;
     d.gamma1[k] = gamma1;
     d.rot[k] = 0.;
+    d.m_coord[k] = phi[k] / max_phi;                                                   // polytrope.rs:139
+    d.rho[k] = std::pow(theta[k], n) * pow3(max_xi) / (max_phi * 4. * kPi);            // :143
   }
   d.u[0] = 3.; d.v[0] = 0.; d.a_star[0] = 0.;
   d.c1[0] = max_phi / pow3(max_xi) * 3.;
+  const double kk = 4. * kPi / (std::pow(d.rho[0], 1. / n - 1.) * (n + 1.) * (max_xi * max_xi));  // :146
+  for (size_t k = 0; k < len; ++k) d.p[k] = std::pow(d.rho[k], 1. + 1. / n) * kk;                 // :147
   return out;
 }
 
@@ -334,6 +350,83 @@ std::vector<Solution> scan(const ContinuousModel& model, const std::vector<doubl
   for (size_t k = 0; k < res.size(); ++k)
     out[k] = Solution{res[k], std::vector<double>(vecs.begin() + k * len, vecs.begin() + (k + 1) * len), ell, m};
   return out;
+}
+
+// ---- post-processing ----
+PostProcessor::PostProcessor(const DiscreteModel& model) : x_(model.dimensionless.r_coord) {
+  const DimensionlessProperties& d = model.dimensionless;
+  storm_model_desc desc{};
+  desc.n_pts = d.r_coord.size();
+  desc.r_coord = d.r_coord.data(); desc.m_coord = d.m_coord.data(); desc.rho = d.rho.data(); desc.p = d.p.data();
+  desc.v = d.v.data(); desc.u = d.u.data(); desc.gamma1 = d.gamma1.data(); desc.a_star = d.a_star.data();
+  desc.c1 = d.c1.data(); desc.rot = d.rot.data();
+  const int rc = storm_postproc_create(&desc, &h_);
+  if (rc != STORM_OK) raise_abi("storm_postproc_create", rc);
+}
+PostProcessor::~PostProcessor() { storm_postproc_destroy(h_); }
+
+std::vector<Rotating1DPostprocessing> PostProcessor::unpack(size_t n, const std::vector<double>& fields,
+                                                            const std::vector<storm_mode_id>& ids,
+                                                            const std::vector<double>& nodes, size_t node_cap) const {
+  const size_t np = x_.size();
+  std::vector<Rotating1DPostprocessing> out(n);
+  for (size_t k = 0; k < n; ++k) {
+    Rotating1DPostprocessing& r = out[k];
+    r.x = x_;
+    if (!fields.empty()) {
+      std::vector<double>* dst[STORM_POST_FIELDS] = {&r.y1, &r.y2, &r.y3, &r.y4, &r.xi_r, &r.xi_h, &r.xi_tn, &r.xi_tp,
+                                                     &r.psi, &r.dpsi, &r.rho, &r.p, &r.chi};
+      for (int f = 0; f < STORM_POST_FIELDS; ++f) {
+        const double* src = fields.data() + (k * STORM_POST_FIELDS + f) * np;
+        dst[f]->assign(src, src + np);
+      }
+    }
+    r.cross_clockwise = ids[k].cross_clockwise;
+    r.cross_counter_clockwise = ids[k].cross_counter_clockwise;
+    r.radial_order = ids[k].radial_order;
+    const size_t nn = ids[k].n_nodes < node_cap ? size_t(ids[k].n_nodes) : node_cap;
+    r.nodes.assign(nodes.begin() + k * node_cap, nodes.begin() + k * node_cap + nn);
+  }
+  return out;
+}
+
+std::vector<Rotating1DPostprocessing> PostProcessor::post_process(const std::vector<Solution>& sols) const {
+  const size_t n = sols.size(), np = x_.size();
+  if (n == 0) return {};
+  std::vector<double> freq(n), vec(n * np * 4);
+  for (size_t k = 0; k < n; ++k) {
+    if (sols[k].ell != sols[0].ell || sols[k].m != sols[0].m)
+      throw std::runtime_error("post_process: one call handles the solutions of one (ell, m)");
+    if (sols[k].eigenvector.size() != np * 4) throw std::runtime_error("post_process: eigenvector is not on the model grid");
+    freq[k] = sols[k].bracket.root;
+    std::memcpy(vec.data() + k * np * 4, sols[k].eigenvector.data(), np * 4 * sizeof(double));
+  }
+  std::vector<double> fields(n * STORM_POST_FIELDS * np), nodes(n * np);
+  std::vector<storm_mode_id> ids(n);
+  const int rc = storm_postprocess_batch(h_, sols[0].ell, sols[0].m, freq.data(), n, vec.data(), fields.data(), ids.data(),
+                                         nodes.data(), np);
+  if (rc != STORM_OK) raise_abi("storm_postprocess_batch", rc);
+  return unpack(n, fields, ids, nodes, np);
+}
+
+std::vector<Rotating1DPostprocessing> PostProcessor::modes(const ErasedSolver& solver, const std::vector<double>& roots,
+                                                           bool want_fields) const {
+  const size_t n = roots.size(), np = x_.size();
+  if (n == 0) return {};
+  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes(n * np);
+  std::vector<storm_mode_id> ids(n);
+  const int rc = storm_modes_batch(solver.handle(), h_, roots.data(), n, nullptr, nullptr,
+                                   want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), np);
+  if (rc != STORM_OK) raise_abi("storm_modes_batch", rc);
+  return unpack(n, fields, ids, nodes, np);
+}
+
+Rotating1DPostprocessing Rotating1DPostprocessing::make(double freq, const std::vector<double>& eigenvector, uint64_t ell,
+                                                        int64_t m, const DiscreteModel& model) {
+  if (eigenvector.size() % 4 != 0) throw std::runtime_error("eigenvector length is not a multiple of 4");
+  PostProcessor pp(model);
+  Solution s{BracketResult{Point{freq, 0.}, Point{freq, 0.}, freq, 0}, eigenvector, ell, m};
+  return std::move(pp.post_process({s})[0]);
 }
 
 }  // namespace storm_host

@@ -12,6 +12,8 @@
 //   Precision                         bracket.rs:19     Precision
 //   ErasedSolver::{new,det,eigenvector,scan_and_optimize}   dynamic_interface.rs:60-160
 //   Model::grid, linspace, rev_linspace, StormState::scan   main.rs:661-679,793-838,1232-1238
+//   Rotating1DPostprocessing::new     postprocessing.rs:58   Rotating1DPostprocessing::make / post_process
+//   StormState::post_process          main.rs:878-899   post_process
 //
 // The Rust host does exactly this work before it reaches the FFI seam: interpolate
 // the model at the collocation abscissae (DiscretizedSystemImpl::new, discretized.rs:81-123) and
@@ -36,8 +38,8 @@ struct DimensionedProperties {  // model.rs:93-102
   double freq_scale() const;    // model.rs:127-129
 };
 
-struct DimensionlessProperties {  // model.rs:70-91 (fields the scan path consumes)
-  std::vector<double> r_coord, v, u, gamma1, a_star, c1, rot;
+struct DimensionlessProperties {  // model.rs:70-91
+  std::vector<double> r_coord, m_coord, rho, p, v, u, gamma1, a_star, c1, rot;
 };
 
 struct DiscreteModel {  // model.rs:6-13
@@ -150,5 +152,39 @@ struct Solution {  // main.rs:1225-1230
 std::vector<Solution> scan(const ContinuousModel& model, const std::vector<double>& solver_grid, uint64_t ell,
                            int64_t m, double lower, double upper, size_t steps, bool inverse, double precision,
                            DifferenceSchemes scheme);
+
+// Rotating1DPostprocessing, postprocessing.rs:14-54.
+struct Rotating1DPostprocessing {
+  std::vector<double> x, y1, y2, y3, y4, xi_r, xi_h, xi_tn, xi_tp, psi, dpsi, rho, p, chi;
+  uint64_t cross_clockwise = 0, cross_counter_clockwise = 0;
+  int64_t radial_order = 0;
+  std::vector<double> nodes;
+  // Rotating1DPostprocessing::new for one mode; `model` is the model evaluated on the solver grid.
+  static Rotating1DPostprocessing make(double freq, const std::vector<double>& eigenvector, uint64_t ell, int64_t m,
+                                       const DiscreteModel& model);
+};
+
+// The model arrays of the post-processing resident on the device (storm_postproc).
+class PostProcessor {
+ public:
+  explicit PostProcessor(const DiscreteModel& model_on_grid);
+  ~PostProcessor();
+  PostProcessor(const PostProcessor&) = delete;
+  PostProcessor& operator=(const PostProcessor&) = delete;
+  // StormState::post_process (main.rs:878-899) over solutions of one (ell, m).
+  std::vector<Rotating1DPostprocessing> post_process(const std::vector<Solution>& solutions) const;
+  // Eigenvectors and post-processing in one device pass (storm_modes_batch); mode ids only unless want_fields.
+  std::vector<Rotating1DPostprocessing> modes(const ErasedSolver& solver, const std::vector<double>& roots,
+                                              bool want_fields) const;
+  size_t len() const { return x_.size(); }
+  storm_postproc* handle() const { return h_; }
+
+ private:
+  std::vector<Rotating1DPostprocessing> unpack(size_t n, const std::vector<double>& fields,
+                                               const std::vector<storm_mode_id>& ids, const std::vector<double>& nodes,
+                                               size_t node_cap) const;
+  storm_postproc* h_ = nullptr;
+  std::vector<double> x_;
+};
 
 }  // namespace storm_host

@@ -9,11 +9,13 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "common_kernels.hpp"
+#include "postprocess.hpp"
 #include "types.hpp"
 
 #define STORM_DECL_SCHEME(ns, n)                                  \
@@ -92,6 +94,8 @@ struct storm_solver {
   int device = 0;
   int scheme = 0;
   bool ell0 = true, uniform = true;
+  uint64_t ell = 0;  // Rotating1D::new(ell, m)
+  int64_t m = 0;
   SystemDev sys{};
   DevBuf<double> tab;
   hipStream_t stream = nullptr;
@@ -112,8 +116,22 @@ struct storm_solver {
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> event_pool;
-  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0};
-  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0};
+  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+  std::mutex mu;
+};
+
+// Model arrays of the post-processing in HBM + per-batch scratch.
+struct storm_postproc {
+  int device = 0;
+  PostModelDev model{};
+  DevBuf<double> tab;
+  hipStream_t stream = nullptr;
+  DevBuf<double> d_freq, d_vec, d_terms, d_scale, d_fields, d_nodes;
+  DevBuf<long long> d_ids;
+  PinnedBuf h_stage;
+  std::vector<long long> h_ids;
+  size_t bytes_max = size_t(1) << 30;  // cap of the per-batch scratch (modes are processed in chunks)
   std::mutex mu;
 };
 
@@ -385,6 +403,113 @@ void refine_all(storm_solver* s, std::vector<BracketState>& br, uint64_t ulp) {
   }
 }
 
+// ---- eigenvectors: shared by storm_eigenvector_batch and storm_modes_batch ----
+// Sizes the staging buffers; returns the number of modes processed per chunk.
+size_t eigen_reserve(storm_solver* s, size_t n) {
+  const size_t n_int = s->sys.n_int;
+  const size_t len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+  const size_t per_mode = (n_int * 16 + ustride + len) * sizeof(double);
+  size_t chunk = s->steps_bytes_max / per_mode;
+  if (chunk == 0) chunk = 1;
+  if (chunk > n) chunk = n;
+  if (chunk > 65535) chunk = 65535;
+  s->d_freq.reserve(chunk); s->d_det.reserve(chunk);
+  s->d_steps.reserve(chunk * n_int * 16 + 16);
+  s->d_upper.reserve(chunk * ustride);
+  s->d_vec.reserve(chunk * len);
+  s->d_swaps.reserve(chunk * 2);
+  return chunk;
+}
+// Eigenvectors of m host frequencies into s->d_vec (and discriminants into s->d_det), left on the device.
+void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
+  hip_check(hipMemcpyAsync(s->d_freq.p, freq, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
+  ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
+  hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
+  tb.stop();
+  ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
+  hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
+                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream), "eigen launch");
+  te.stop();
+  count_launch(s, 3);
+  s->stats.eigenvectors += m;
+}
+
+// ---- post-processing ----
+// src/gaunt.rs:1-17,32-37,46-51 (host code of this file is compiled -ffp-contract=off as well).
+double gaunt_beta(uint64_t k, int64_t m) {
+  const double kf = double(k), mf = double(m);
+  return std::sqrt((kf * kf - mf * mf) / (4. * kf * kf - 1.));
+}
+double gaunt_q_kl1(uint64_t k, uint64_t l, int64_t m) {
+  const double sign = (m % 2 == 0) ? 1.0 : -1.0;  // (-1)^(m % 2); (-1)^-1 = 1/(-1) = -1
+  return sign * (k == l + 1 ? gaunt_beta(k, m) : (l == k + 1 ? gaunt_beta(l, m) : 0.));
+}
+double gaunt_q_kl1_h(uint64_t k, uint64_t l, int64_t m) {
+  const double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return gaunt_q_kl1(k, l, m) * ((lk + ll) / 2. - 1.);
+}
+double gaunt_q_kl1_hd(uint64_t k, uint64_t l, int64_t m) {
+  const double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return gaunt_q_kl1(k, l, m) * ((ll - lk) / 2. + 1.);
+}
+PostParams post_params(uint64_t ell, int64_t m) {  // src/postprocessing.rs:85-95
+  if (ell > 1000000) fail(STORM_ERR_INVALID_ARGUMENT, "ell does not fit (the reference converts it to i32)");
+  const uint64_t n1 = ell == 0 ? 0 : ell - 1;
+  const uint64_t m_abs = m < 0 ? uint64_t(0) - uint64_t(m) : uint64_t(m);
+  PostParams q;
+  q.ell = int(ell);
+  q.tn_zero = (m_abs == ell || ell == 1) ? 1 : 0;
+  q.lambda = double(ell * (ell + 1));
+  q.lambda_n1 = double(ell * n1);
+  q.lambda_p1 = double((ell + 2) * (ell + 1));
+  q.q_hd_n = gaunt_q_kl1_hd(ell, n1, m);
+  q.q_hd_p = gaunt_q_kl1_hd(ell, ell + 1, m);
+  q.q_h_n = gaunt_q_kl1_h(ell, n1, m);
+  q.q_h_p = gaunt_q_kl1_h(ell, ell + 1, m);
+  q.mf = double(m);
+  q.ellf = double(ell);
+  return q;
+}
+size_t post_reserve(storm_postproc* p, size_t n, bool fields, size_t node_cap) {
+  const size_t np = p->model.n_pts;
+  const size_t per_mode = (np * (1 + 4 + (fields ? kPostFields : 0)) + node_cap + 8) * sizeof(double);
+  size_t chunk = p->bytes_max / per_mode;
+  if (chunk == 0) chunk = 1;
+  if (chunk > n) chunk = n;
+  if (chunk > 65535) chunk = 65535;
+  p->d_terms.reserve(chunk * np);
+  p->d_scale.reserve(chunk);
+  p->d_ids.reserve(chunk * 4);
+  if (fields) p->d_fields.reserve(chunk * kPostFields * np);
+  if (node_cap) p->d_nodes.reserve(chunk * node_cap);
+  return chunk;
+}
+void post_chunk(storm_postproc* p, const PostParams& par, const double* d_freq, const double* d_vec, size_t k, bool fields,
+                size_t node_cap, hipStream_t st) {
+  PostArgs a;
+  a.model = p->model; a.par = par; a.freq = d_freq; a.vec = d_vec; a.n = k;
+  a.terms = p->d_terms.p; a.scale = p->d_scale.p; a.fields = fields ? p->d_fields.p : nullptr;
+  a.ids = p->d_ids.p; a.nodes = node_cap ? p->d_nodes.p : nullptr; a.node_cap = node_cap; a.stream = st;
+  hip_check(launch_postprocess(a), "postprocess launch");
+}
+// Copies the results of the last post_chunk to the caller (synchronises st).
+void post_download(storm_postproc* p, size_t k, double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap,
+                   hipStream_t st) {
+  const size_t np = p->model.n_pts;
+  const size_t nf = fields_out ? k * kPostFields * np : 0, nn = nodes_out ? k * node_cap : 0;
+  p->h_stage.reserve(nf + nn + 1);
+  p->h_ids.resize(k * 4);
+  if (nf) hip_check(hipMemcpyAsync(p->h_stage.p, p->d_fields.p, nf * sizeof(double), hipMemcpyDeviceToHost, st), "fields D2H");
+  if (nn) hip_check(hipMemcpyAsync(p->h_stage.p + nf, p->d_nodes.p, nn * sizeof(double), hipMemcpyDeviceToHost, st), "nodes D2H");
+  hip_check(hipMemcpyAsync(p->h_ids.data(), p->d_ids.p, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, st), "ids D2H");
+  hip_check(hipStreamSynchronize(st), "postprocess");
+  if (nf) std::memcpy(fields_out, p->h_stage.p, nf * sizeof(double));
+  if (nn) std::memcpy(nodes_out, p->h_stage.p + nf, nn * sizeof(double));
+  for (size_t i = 0; i < k; ++i)
+    ids_out[i] = storm_mode_id{uint64_t(p->h_ids[i * 4]), uint64_t(p->h_ids[i * 4 + 1]), int64_t(p->h_ids[i * 4 + 2]),
+                               uint64_t(p->h_ids[i * 4 + 3])};
+}
+
 }  // namespace
 
 extern "C" {
@@ -439,6 +564,7 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     s->sys.stride = padded_stride(d->n_int);
     s->sys.plane = s->sys.stride * d->p;
     s->sys.n_int = d->n_int;
+    s->ell = d->ell; s->m = d->m;
     s->sys.ell = ell;
     s->sys.lambda = ell * (ell + 1.0);
     s->sys.inner_c1 = d->inner_c1;
@@ -592,36 +718,117 @@ int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, doubl
     if (n == 0) return;
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard g(s->device);
-    const size_t n_int = s->sys.n_int;
-    const size_t len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
-    const size_t per_mode = (n_int * 16 + ustride + len) * sizeof(double);
-    size_t chunk = s->steps_bytes_max / per_mode;
-    if (chunk == 0) chunk = 1;
-    if (chunk > n) chunk = n;
-    if (chunk > 65535) chunk = 65535;
-    s->d_freq.reserve(chunk); s->d_det.reserve(chunk);
-    s->d_steps.reserve(chunk * n_int * 16 + 16);
-    s->d_upper.reserve(chunk * ustride);
-    s->d_vec.reserve(chunk * len);
-    s->d_swaps.reserve(chunk * 2);
+    const size_t len = (s->sys.n_int + 1) * 4;
+    const size_t chunk = eigen_reserve(s, n);
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
-      hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
-      ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
-      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
-      tb.stop();
-      ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
-      hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p, s->d_swaps.p, s->d_det.p,
-                             s->d_vec.p, s->stream), "eigen launch");
-      te.stop();
-      count_launch(s, 3);
+      eigen_chunk(s, freq + off, m);
       s->h_vec.reserve(m * len);
       hip_check(hipMemcpyAsync(s->h_vec.p, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
       if (det_out)
         hip_check(hipMemcpyAsync(det_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
       check_flags(s);
       std::memcpy(vec_out + off * len, s->h_vec.p, m * len * sizeof(double));
-      s->stats.eigenvectors += m;
+    }
+  });
+}
+
+int storm_postproc_create(const storm_model_desc* d, storm_postproc** out) {
+  return guarded([&] {
+    if (!d || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const double* src[10] = {d->r_coord, d->m_coord, d->rho, d->p, d->v, d->u, d->gamma1, d->a_star, d->c1, d->rot};
+    for (const double* q : src)
+      if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null model array");
+    const size_t np = d->n_pts;
+    if (np < 2) fail(STORM_ERR_INVALID_ARGUMENT, "the model needs at least two points");
+    if (d->r_coord[0] != 0.0) fail(STORM_ERR_INVALID_ARGUMENT, "r_coord[0] must be 0 (assert_eq! in Rotating1DPostprocessing::new)");
+    std::vector<double> tab(size_t(kPostPlanes) * np);
+    static_assert(PP_R == 0 && PP_ROT == 9 && PP_TRAP == 10, "plane order");
+    for (int f = 0; f < 10; ++f) std::memcpy(tab.data() + size_t(f) * np, src[f], np * sizeof(double));
+    double* trap = tab.data() + size_t(PP_TRAP) * np;  // src/postprocessing.rs:99-111
+    const double* r = d->r_coord;
+    trap[0] = 0.5 * (r[1] - r[0]);
+    trap[np - 1] = 0.5 * (r[np - 1] - r[np - 2]);
+    for (size_t i = 1; i + 1 < np; ++i) trap[i] = 0.5 * (r[i + 1] - r[i - 1]);
+    std::unique_ptr<storm_postproc> p(new storm_postproc());
+    hip_check(hipGetDevice(&p->device), "hipGetDevice (is a HIP device present?)");
+    hip_check(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking), "hipStreamCreate");
+    p->tab.reserve(tab.size());
+    hip_check(hipMemcpyAsync(p->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, p->stream), "model H2D");
+    hip_check(hipStreamSynchronize(p->stream), "model upload");
+    p->model.tab = p->tab.p;
+    p->model.n_pts = np;
+    *out = p.release();
+  });
+}
+
+void storm_postproc_destroy(storm_postproc* p) {
+  if (!p) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(p->device);
+  if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+  p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
+  p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
+  (void)hipSetDevice(prev);
+  delete p;
+}
+
+int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const double* freq, size_t n, const double* vec,
+                            double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {
+  return guarded([&] {
+    if (!p || (n && (!freq || !vec || !ids_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(p->mu);
+    DeviceGuard g(p->device);
+    const PostParams par = post_params(ell, m);
+    const size_t np = p->model.n_pts, len = np * 4;
+    const size_t chunk = post_reserve(p, n, fields_out != nullptr, nodes_out ? node_cap : 0);
+    p->d_freq.reserve(chunk);
+    p->d_vec.reserve(chunk * len);
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t k = std::min(chunk, n - off);
+      hip_check(hipMemcpyAsync(p->d_freq.p, freq + off, k * sizeof(double), hipMemcpyHostToDevice, p->stream), "freq H2D");
+      hip_check(hipMemcpyAsync(p->d_vec.p, vec + off * len, k * len * sizeof(double), hipMemcpyHostToDevice, p->stream), "vec H2D");
+      post_chunk(p, par, p->d_freq.p, p->d_vec.p, k, fields_out != nullptr, nodes_out ? node_cap : 0, p->stream);
+      post_download(p, k, fields_out ? fields_out + off * kPostFields * np : nullptr, ids_out + off,
+                    nodes_out ? nodes_out + off * node_cap : nullptr, node_cap, p->stream);
+    }
+  });
+}
+
+int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, size_t n, double* det_out, double* vec_out,
+                      double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {
+  return guarded([&] {
+    if (!s || !p || (n && (!freq || !ids_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->sys.n_int + 1 != p->model.n_pts)
+      fail(STORM_ERR_INVALID_ARGUMENT, "the solver grid is not the post-processing model's grid (n_int + 1 != n_pts)");
+    if (s->device != p->device) fail(STORM_ERR_INVALID_ARGUMENT, "solver and post-processing handle live on different devices");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock_s(s->mu);  // lock order: solver, then post-processing handle
+    std::lock_guard<std::mutex> lock_p(p->mu);
+    DeviceGuard g(s->device);
+    const PostParams par = post_params(s->ell, s->m);
+    const size_t np = p->model.n_pts, len = np * 4;
+    size_t chunk = std::min(eigen_reserve(s, n), post_reserve(p, n, fields_out != nullptr, nodes_out ? node_cap : 0));
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t k = std::min(chunk, n - off);
+      eigen_chunk(s, freq + off, k);
+      ScopedTimer tp(s, s->stream, STORM_KERNEL_POSTPROCESS);
+      post_chunk(p, par, s->d_freq.p, s->d_vec.p, k, fields_out != nullptr, nodes_out ? node_cap : 0, s->stream);
+      tp.stop();
+      count_launch(s, fields_out ? 3 : 2);
+      if (vec_out) {
+        s->h_vec.reserve(k * len);
+        hip_check(hipMemcpyAsync(s->h_vec.p, s->d_vec.p, k * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
+      }
+      if (det_out)
+        hip_check(hipMemcpyAsync(det_out + off, s->d_det.p, k * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
+      post_download(p, k, fields_out ? fields_out + off * kPostFields * np : nullptr, ids_out + off,
+                    nodes_out ? nodes_out + off * node_cap : nullptr, node_cap, s->stream);
+      check_flags(s);  // synchronises the stream
+      if (vec_out) std::memcpy(vec_out + off * len, s->h_vec.p, k * len * sizeof(double));
     }
   });
 }

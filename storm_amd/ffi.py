@@ -36,11 +36,25 @@ class Stats(C.Structure):
                 ("eigenvectors", C.c_uint64), ("launches", C.c_uint64)]
 
 
+class ModelDesc(C.Structure):
+    _fields_ = [("n_pts", C.c_size_t)] + [(k, _dp) for k in ("r_coord", "m_coord", "rho", "p", "v", "u", "gamma1",
+                                                               "a_star", "c1", "rot")]
+
+
+class ModeId(C.Structure):
+    _fields_ = [("cross_clockwise", C.c_uint64), ("cross_counter_clockwise", C.c_uint64),
+                ("radial_order", C.c_int64), ("n_nodes", C.c_uint64)]
+
+
+MODEL_FIELDS = ["r_coord", "m_coord", "rho", "p", "v", "u", "gamma1", "a_star", "c1", "rot"]
+POST_FIELDS = ["y1", "y2", "y3", "y4", "xi_r", "xi_h", "xi_tn", "xi_tp", "psi", "dpsi", "rho", "p", "chi"]
+
 # every symbol include/storm_hip.h declares
 EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "storm_det_batch_device",
            "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
            "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
-           "storm_version"]
+           "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postprocess_batch",
+           "storm_modes_batch"]
 
 _lib = None
 
@@ -72,11 +86,18 @@ def load_library():
     L.storm_solver_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.storm_solver_n_int.restype = C.c_size_t
     L.storm_solver_n_int.argtypes = [C.c_void_p]
+    L.storm_postproc_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
+    L.storm_postproc_destroy.argtypes = [C.c_void_p]
+    L.storm_postproc_destroy.restype = None
+    L.storm_postprocess_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, C.c_size_t, _dp, _dp,
+                                          C.POINTER(ModeId), _dp, C.c_size_t]
+    L.storm_modes_batch.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, _dp, C.POINTER(ModeId), _dp,
+                                    C.c_size_t]
     _lib = L
     return L
 
 
-KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad", "det_hex"]
+KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad", "det_hex", "postprocess"]
 
 
 def kernel_times(handle, reset=False):
@@ -176,3 +197,69 @@ class HipSolver:
         vec = np.empty((f.size, (self.n_int + 1) * 4))
         _check(load_library().storm_eigenvector_batch(self._h, _p(f), f.size, _p(dets), _p(vec)))
         return dets, vec
+
+    def modes(self, post, freqs, want_vec=False, want_fields=True, node_cap=None):
+        """storm_modes_batch: eigenvectors + post-processing with the eigenvectors staying on the device."""
+        f = _f64(np.atleast_1d(freqs))
+        npts = post.n_pts
+        cap = npts if node_cap is None else node_cap
+        dets = np.empty(f.size)
+        vec = np.empty((f.size, npts * 4)) if want_vec else None
+        fields = np.empty((f.size, len(POST_FIELDS), npts)) if want_fields else None
+        ids = (ModeId * max(f.size, 1))()
+        nodes = np.full((f.size, max(cap, 1)), np.nan)
+        _check(load_library().storm_modes_batch(self._h, post._h, _p(f), f.size, _p(dets), _p(vec) if want_vec else None,
+                                                _p(fields) if want_fields else None, ids, _p(nodes) if cap else None, cap))
+        out = _post_result(f.size, fields, ids, nodes, cap)
+        out["det"] = dets
+        out["vec"] = vec
+        return out
+
+
+def _post_result(n, fields, ids, nodes, cap):
+    idarr = np.array([[i.cross_clockwise, i.cross_counter_clockwise, i.radial_order] for i in ids[:n]],
+                     dtype=np.int64).reshape(n, 3)
+    nn = np.array([i.n_nodes for i in ids[:n]], dtype=np.int64)
+    return dict(fields=fields, ids=idarr, n_nodes=nn, nodes=[nodes[k, :min(int(nn[k]), cap)].copy() for k in range(n)])
+
+
+class HipPostproc:
+    """One storm_postproc handle: the model (evaluated on the solver grid) resident on the device.
+    `model` maps the names of MODEL_FIELDS to arrays of equal length."""
+
+    def __init__(self, model):
+        arrs = {k: _f64(model[k]) for k in MODEL_FIELDS}
+        n = arrs["r_coord"].size
+        for k, a in arrs.items():
+            if a.size != n:
+                raise ValueError(f"{k}: expected {n} entries, got {a.size}")
+        d = ModelDesc(n, *[_p(arrs[k]) for k in MODEL_FIELDS])
+        h = C.c_void_p()
+        _check(load_library().storm_postproc_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.n_pts = n
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().storm_postproc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def postprocess(self, ell, m, freqs, vecs, want_fields=True, node_cap=None):
+        """storm_postprocess_batch on host eigenvectors [n][n_pts*4]."""
+        f = _f64(np.atleast_1d(freqs))
+        v = _f64(vecs).reshape(f.size, -1) if f.size else np.empty((0, self.n_pts * 4))
+        if f.size and v.shape[1] != self.n_pts * 4:
+            raise ValueError("eigenvectors do not live on the model grid")
+        cap = self.n_pts if node_cap is None else node_cap
+        fields = np.empty((f.size, len(POST_FIELDS), self.n_pts)) if want_fields else None
+        ids = (ModeId * max(f.size, 1))()
+        nodes = np.full((f.size, max(cap, 1)), np.nan)
+        _check(load_library().storm_postprocess_batch(self._h, ell, m, _p(f), f.size, _p(v), _p(fields) if want_fields else None,
+                                                      ids, _p(nodes) if cap else None, cap))
+        return _post_result(f.size, fields, ids, nodes, cap)

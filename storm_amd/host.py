@@ -61,6 +61,15 @@ def load_host_library():
     L.storm_host_polytrope0_exact.restype = C.c_double
     L.storm_host_polytrope0_exact.argtypes = [C.c_double, C.c_uint64, C.c_int64]
     L.storm_host_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
+    L.storm_host_model_eval.restype = C.c_void_p
+    L.storm_host_model_eval.argtypes = [C.c_void_p, _dp, C.c_size_t]
+    L.storm_host_postproc_new.restype = C.c_void_p
+    L.storm_host_postproc_new.argtypes = [C.c_void_p]
+    L.storm_host_postproc_free.argtypes = [C.c_void_p]
+    _i64p, _u64p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    L.storm_host_post_process.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, _dp, C.c_size_t, _dp, _i64p, _u64p,
+                                          _dp, C.c_size_t]
+    L.storm_host_modes.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _i64p, _u64p, _dp, C.c_size_t]
     L.storm_host_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
     _lib = L
     return L
@@ -109,7 +118,7 @@ class Precision:
 
 class Model:
     """DiscreteModel / ContinuousModel handle on the C++ host side."""
-    FIELDS = ["r_coord", "v", "u", "gamma1", "a_star", "c1", "rot"]
+    FIELDS = ["r_coord", "v", "u", "gamma1", "a_star", "c1", "rot", "m_coord", "rho", "p"]
 
     def __init__(self, handle, poly0=False):
         if not handle:
@@ -155,6 +164,11 @@ class Model:
         out = np.empty(n)
         L.storm_host_model_grid(self._h, scale, _p(out), n)
         return out
+
+    def eval(self, grid):
+        """ContinuousModel::eval on `grid` (what post-process evaluates, reference src/main.rs:892)."""
+        g = _f64(grid)
+        return Model(load_host_library().storm_host_model_eval(self._h, _p(g), g.size))
 
     def __del__(self):
         try:
@@ -250,6 +264,62 @@ def scan(model, solver_grid, ell, m, lower, upper, steps, inverse=False, precisi
     res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals))
            for b in out[:n]]
     return res, vec[:n].copy()
+
+
+POST_FIELDS = ffi.POST_FIELDS
+
+
+class PostProcessor:
+    """StormState::post_process (reference src/main.rs:878-899) on the device: Rotating1DPostprocessing::new
+    for every solution.  `model_on_grid` = model.eval(solver_grid)."""
+
+    def __init__(self, model_on_grid):
+        h = load_host_library().storm_host_postproc_new(model_on_grid._h)
+        if not h:
+            raise _err()
+        self._h = C.c_void_p(h)
+        self._model = model_on_grid
+        self.n_pts = len(model_on_grid)
+
+    def _buffers(self, n, want_fields):
+        fields = np.empty((n, len(POST_FIELDS), self.n_pts)) if want_fields else None
+        ids = np.empty((n, 3), dtype=np.int64)
+        nn = np.zeros(n, dtype=np.uint64)
+        nodes = np.full((n, self.n_pts), np.nan)
+        return fields, ids, nn, nodes
+
+    @staticmethod
+    def _result(fields, ids, nn, nodes):
+        return dict(fields=fields, ids=ids, n_nodes=nn.astype(np.int64),
+                    nodes=[nodes[k, :int(nn[k])].copy() for k in range(len(nn))])
+
+    def post_process(self, ell, m, roots, eigenvectors):
+        f = _f64(np.atleast_1d(roots))
+        v = _f64(eigenvectors).reshape(f.size, -1)
+        fields, ids, nn, nodes = self._buffers(f.size, True)
+        rc = load_host_library().storm_host_post_process(
+            self._h, ell, m, _p(f), _p(v), f.size, _p(fields), ids.ctypes.data_as(C.POINTER(C.c_int64)),
+            nn.ctypes.data_as(C.POINTER(C.c_uint64)), _p(nodes), self.n_pts)
+        if rc != 0:
+            raise _err()
+        return self._result(fields, ids, nn, nodes)
+
+    def modes(self, solver, roots, want_fields=False):
+        """Eigenvectors + post-processing in one device pass (eigenvectors never leave HBM)."""
+        f = _f64(np.atleast_1d(roots))
+        fields, ids, nn, nodes = self._buffers(f.size, want_fields)
+        rc = load_host_library().storm_host_modes(
+            self._h, solver._h, _p(f), f.size, 1 if want_fields else 0, _p(fields) if want_fields else None,
+            ids.ctypes.data_as(C.POINTER(C.c_int64)), nn.ctypes.data_as(C.POINTER(C.c_uint64)), _p(nodes), self.n_pts)
+        if rc != 0:
+            raise _err()
+        return self._result(fields, ids, nn, nodes)
+
+    def __del__(self):
+        try:
+            load_host_library().storm_host_postproc_free(self._h)
+        except Exception:
+            pass
 
 
 def polytrope0_exact(gamma1, ell, radial_order):

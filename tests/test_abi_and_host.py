@@ -44,6 +44,23 @@ def test_argument_validation_without_gpu():
     assert L.storm_det_batch(None, None, 0, None) == -1
 
 
+def test_postproc_argument_validation_without_gpu():
+    from storm_amd import ffi
+    L = ffi.load_library()
+    h = C.c_void_p()
+    assert L.storm_postproc_create(None, C.byref(h)) == -1
+    d = ffi.ModelDesc()
+    d.n_pts = 4
+    assert L.storm_postproc_create(C.byref(d), C.byref(h)) == -1     # null arrays
+    a = np.array([0.1, 0.2, 0.3, 0.4])
+    p = a.ctypes.data_as(C.POINTER(C.c_double))
+    d = ffi.ModelDesc(4, *([p] * 10))
+    assert L.storm_postproc_create(C.byref(d), C.byref(h)) == -1     # r_coord[0] != 0
+    assert b"r_coord[0]" in L.storm_last_error()
+    L.storm_postproc_destroy(None)
+    assert L.storm_modes_batch(None, None, None, 0, None, None, None, None, None, 0) == -1
+
+
 def test_no_cpu_fallback_when_no_gpu():
     """Without a HIP device creation must fail with STORM_ERR_HIP, never compute on the CPU."""
     import torch
@@ -56,6 +73,10 @@ def test_no_cpu_fallback_when_no_gpu():
     d = ffi.SystemDesc(0, 0, 0, 1, 1, p, p, p, p, p, p, 1.0, 0.0, 3.0)
     h = C.c_void_p()
     assert L.storm_solver_create(C.byref(d), C.byref(h)) == -2
+    assert not h.value
+    r = np.array([0.0, 0.5, 1.0])
+    md = ffi.ModelDesc(3, *([r.ctypes.data_as(C.POINTER(C.c_double))] * 10))
+    assert L.storm_postproc_create(C.byref(md), C.byref(h)) == -2
     assert not h.value
 
 
@@ -76,6 +97,10 @@ def test_host_model_matches_oracle(oracle, oracle_models, golden_dir, name):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), f
     for scale in (1, 3):
         assert np.array_equal(hm.grid(scale), om.grid(scale))
+    g = hm.grid(2)   # the model on a resampled solver grid, as post-process evaluates it (src/main.rs:892)
+    he, oe = hm.eval(g), om.eval(g)
+    for f in host.Model.FIELDS:
+        assert np.array_equal(he.field(f).view(np.uint64), oe.field(f).view(np.uint64)), f
 
 
 def test_host_polytrope_matches_oracle(oracle):

@@ -57,6 +57,57 @@ def test_mode_ids(oracle, oracle_models, known_answers, name):
     u = model.field("u")
     got = [list(mode_id(v, ell, u)) for v in vecs]
     assert got == ka["expected"]
+    # the same through the oracle's full Rotating1DPostprocessing::new (src/postprocessing.rs:58-301), which is
+    # what the reference test calls: pins the normalisation + count_windings restatement
+    post = model.postprocess(ell, m, roots, vecs, threads=8)
+    assert post["ids"].tolist() == ka["expected"]
+    assert [len(n) for n in post["nodes"]] == [e[0] + e[1] for e in ka["expected"]]
+
+
+def test_postprocess_properties(oracle, oracle_models):
+    # properties the reference's definitions imply (no reference test asserts the field values: parity unpinned)
+    model = oracle_models("zams")
+    grid = model.field("r_coord")
+    r, rho = grid, model.field("rho")
+    for ell, m, rot in ((0, 0, 0.0), (1, 0, 0.0), (2, 1, 0.05), (3, -2, 0.05)):
+        model.set_rotation_constant(rot)
+        solver = oracle.Solver(model, ell, m, "colloc4", grid)
+        res, _, _ = solver.scan_and_optimize(oracle.linspace(3.0, 9.0, 40), oracle.relative_to_ulp(1e-10), threads=8)
+        assert res
+        roots = np.array([b["root"] for b in res])
+        _, vecs = solver.eigenvector(roots, threads=8)
+        post = model.postprocess(ell, m, roots, vecs, threads=8)
+        F = {k: post["fields"][:, i, :] for i, k in enumerate(oracle.POST_FIELDS)}
+        lam = ell * (ell + 1)
+        trap = np.empty_like(r)
+        trap[0], trap[-1] = 0.5 * (r[1] - r[0]), 0.5 * (r[-1] - r[-2])
+        trap[1:-1] = 0.5 * (r[2:] - r[:-2])
+        inertia = np.sum((rho * r * r * (F["xi_r"] ** 2 + lam * F["xi_h"] ** 2) * trap)[:, 1:], axis=1)
+        np.testing.assert_allclose(inertia, 1.0, rtol=1e-12)            # unit mode inertia after normalisation
+        for k, v in enumerate(vecs):                                       # y's are the eigenvector, rescaled
+            e = v.reshape(-1, 4)
+            scale = F["y4"][k, -1] / e[-1, 3]
+            np.testing.assert_allclose(F["y1"][k], e[:, 0] * scale, rtol=1e-15, atol=0)
+        if ell == 0:
+            assert np.all(F["xi_h"] == 0.0) and np.all(F["xi_tn"] == 0.0)
+        if rot == 0.0:
+            assert np.all(F["xi_tp"] == 0.0)
+        for k, nodes in enumerate(post["nodes"]):
+            assert len(nodes) == post["ids"][k, 0] + post["ids"][k, 1]
+            assert np.all(np.diff(nodes) > 0) and np.all((nodes > 0) & (nodes < 1))
+    model.set_rotation_constant(0.0)
+
+
+def test_powi_and_gaunt(oracle):
+    # f64::powi (compiler-builtins __powidf2) and src/gaunt.rs
+    assert oracle.powi(3.0, 0) == 1.0 and oracle.powi(3.0, 1) == 3.0 and oracle.powi(3.0, -1) == 1.0 / 3.0
+    assert oracle.powi(1.1, 5) == (1.1 * ((1.1 * 1.1) * (1.1 * 1.1)))
+    assert oracle.powi(0.7, -2) == 1.0 / (0.7 * 0.7)
+    q = oracle.gaunt(2, 1)   # k=2: l=1 and l=3, m=1 -> sign -1
+    b2, b3 = np.sqrt((4 - 1) / (16 - 1.0)), np.sqrt((9 - 1) / (36 - 1.0))
+    np.testing.assert_allclose(q, [-b2 * ((2 - 6) / 2 + 1), -b3 * ((12 - 6) / 2 + 1), -b2 * ((6 + 2) / 2 - 1),
+                                   -b3 * ((6 + 12) / 2 - 1)], rtol=1e-15)
+    assert np.all(oracle.gaunt(0, 0)[[0, 2]] == 0.0)
 
 
 def test_ulp_conversion(oracle):
