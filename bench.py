@@ -36,7 +36,7 @@ FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "collo
                   "magnus2": 1486.0, "magnus4": 1848.0, "magnus6": 2562.0, "magnus8": 3900.1}
 # HBM bytes per launch of the dominant kernels, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 # (profiles/r01_pmc_det_hex_colloc8.txt; raw counters in KB, no width correction applied).
-TRAFFIC = {"det_hex<colloc8>": 9890.85e3 + 78.125e3}
+TRAFFIC = {"det_hex<colloc8>": 10871.2e3 + 156.25e3}
 PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz); = dense FP64 MFMA peak
 
 # longest jobs first (colloc8 costs ~2x magnus6) so their latency-bound tails overlap the other scans
@@ -258,6 +258,39 @@ def main():
     res = measure(main_arith, args.steps, args.warmup)
     other = measure(1 - main_arith, max(1, min(args.steps, 2)), 1) if not args.single_mode else None
     elapsed, modes, det_evals, refine, eigs = res["elapsed"], res["modes"], res["det_evals"], res["refine"], res["eigs"]
+
+    # Next-row leg (outside the timed region and outside `value`): eigenvectors + device
+    # post-processing of one scan's modes with nothing but the mode ids crossing PCIe (storm_modes_batch).
+    post = None
+    if rank == 0:
+        for s in solvers:
+            s.set_option("arithmetic", 0)
+        sd = solvers[0]
+        lo, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
+        roots = np.array([b["root"] for b in raws[0].scan_and_optimize(mine, ulp)[0]])
+        if roots.size:
+            pp = host.PostProcessor(model.eval(grid))
+            pp.modes(sd, roots)
+            reps = 5
+            sd.kernel_times(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ids = pp.modes(sd, roots)["ids"]
+            wall = (time.perf_counter() - t0) / reps
+            kt = sd.kernel_times(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sd.eigenvector(roots)
+            wall_eig = (time.perf_counter() - t0) / reps
+            k_ms = kt["postprocess"][0] / reps
+            alg = roots.size * grid.size * 80.0   # terms: 32 B vector + 8 B out; modes: 8 B term + 32 B vector
+            post = {"modes": int(roots.size), "n_pts": int(grid.size),
+                    "ms_eigenvectors_plus_ids": round(wall * 1e3, 3), "ms_eigenvectors_to_host": round(wall_eig * 1e3, 3),
+                    "postprocess_kernels_ms": round(k_ms, 4), "eigen_kernels_ms": round(kt["eigen"][0] / reps, 3),
+                    "algorithmic_GB_per_s": round(alg / (k_ms * 1e-3) / 1e9, 1) if k_ms else None, "hbm_peak_GB_per_s": 8000,
+                    "radial_orders": [int(ids[0, 2]), int(ids[-1, 2])],
+                    "note": "latency-bound at this batch size: one wave per mode sums the norm integrand in index "
+                            "order (bit-exact parity), ~0.1 ms regardless of the number of modes"}
     kernel_summary, roofline = res["kernels"], res["roofline"]
 
     if rank == 0:
@@ -274,6 +307,7 @@ def main():
             "modes_per_s": modes * args.steps / elapsed if False else (eigs / elapsed),
             "modes_per_step": modes, "det_evals": det_evals, "refine_evals": refine,
             "arithmetic": args.arithmetic, "kernels": kernel_summary, "roofline": roofline,
+            "post_processing": post,
         }
         if other is not None:
             oname = "parity" if main_arith else "fast"
