@@ -148,6 +148,34 @@ int storm_postprocess_batch(storm_postproc* post, uint64_t ell, int64_t m, const
 int storm_modes_batch(storm_solver* solver, storm_postproc* post, const double* freq, size_t n, double* det_out,
                       double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap);
 
+/* ---- Mode coupling of the deformed star (`perturb-deformed`, src/main.rs:901-940) ----
+ *
+ * PerturbedMetric (src/model.rs:104-123) as produced by perturb_structure (src/perturbed.rs:324-460, stays on the
+ * host): six arrays of n_pts values on the post-processing handle's grid.  Host pointers. */
+typedef struct {
+  const double *alpha, *dalpha, *ddalpha, *beta, *dbeta, *ddbeta;
+} storm_metric_desc;
+
+/* Order of the matrices in `out`. */
+typedef enum {
+  STORM_COUPLING_D_SQUARED = 0, STORM_COUPLING_D_LINEAR, STORM_COUPLING_D_ZERO, STORM_COUPLING_R_LINEAR,
+  STORM_COUPLING_R_ZERO, STORM_COUPLING_L_ZERO, STORM_COUPLING_MATRICES = 6
+} storm_coupling_matrix;
+
+/* Replaces the (left, right, radius) triple loop of perturb_deformed (src/perturbed.rs:110-263): the six n x n
+ * coupling matrices of n modes with azimuthal order m.  ell[k], freq[k] = ModeToPerturb::{ell, freq}
+ * (src/perturbed.rs:26-33); fields = the modes' post-processing results, [n][STORM_POST_FIELDS][n_pts] exactly as
+ * storm_postprocess_batch / storm_modes_batch write them.  out is [STORM_COUPLING_MATRICES][n*n], each matrix
+ * column-major like nalgebra's DMatrix: element (left, right) at left + right*n.  The generalised eigenproblem built
+ * from them (src/perturbed.rs:265-320, src/linalg/qz.rs) stays with the caller.  STORM_ERR_NON_FINITE where the
+ * reference's assert!(.. .is_finite()) would fire (src/perturbed.rs:165-170,188-199,253-260). */
+int storm_coupling_matrices(storm_postproc* post, size_t n, const uint64_t* ell, const double* freq,
+                            const double* fields, int64_t m, const storm_metric_desc* metric, double* out);
+
+/* Device time in ms (HIP events on the launch stream) of the coupling kernel of the last storm_coupling_matrices call
+ * on this handle; measurement aid, no counterpart in the reference. */
+double storm_postproc_last_kernel_ms(const storm_postproc* post);
+
 /* Precision::Relative(p).as_ulp(), src/bracket.rs:30-40. */
 uint64_t storm_precision_relative_to_ulp(double relative_precision);
 

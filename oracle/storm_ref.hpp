@@ -27,6 +27,7 @@
 #include <cstring>
 #include <limits>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -1183,6 +1184,218 @@ inline Postprocessing postprocess(double freq, const double* eigenvector, size_t
   out.cross_clockwise = w.clockwise; out.cross_counter_clockwise = w.counter_clockwise;
   out.nodes = std::move(w.nodes);
   return out;
+}
+
+// ---------------------------------------------------------------------------
+// Mode coupling integrals of the deformed star.
+// perturb_deformed, src/perturbed.rs:56-263: the six M x M matrices; the generalised eigenproblem built
+// from them (src/perturbed.rs:265-320, src/linalg/qz.rs) stays with the host and is not restated.
+// Pinned by nothing in the reference (its only test is #[ignore]d "used for output"): parity unpinned.
+// ---------------------------------------------------------------------------
+inline double q_kl2(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:19-30
+  double v;
+  if (k == l) { double a = beta_k(k + 1, m), b = beta_k(k, m); v = a * a + b * b - 1. / 3.; }
+  else if (k == l + 2) v = beta_k(k, m) * beta_k(l + 1, m);
+  else if (k + 2 == l) v = beta_k(k + 1, m) * beta_k(l, m);
+  else v = 0.;
+  return (3. / 2.) * v;
+}
+inline double q_kl2_h(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:39-44
+  double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return q_kl2(k, l, m) * ((lk + ll) / 2. - 3.);
+}
+inline double q_kl2_hd(uint64_t k, uint64_t l, int64_t m) {  // gaunt.rs:53-58
+  double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return q_kl2(k, l, m) * ((ll - lk) / 2. + 3.);
+}
+
+struct PerturbedMetric { std::vector<double> alpha, dalpha, ddalpha, beta, dbeta, ddbeta; };  // model.rs:104-123
+struct ModeToPerturb {  // perturbed.rs:26-33; the post-processing members perturb_deformed reads
+  uint64_t ell;
+  double freq;
+  const double *xi_r, *xi_h, *xi_tn, *xi_tp, *psi, *rho, *p;
+};
+enum CouplingMatrix { CM_D_SQUARED, CM_D_LINEAR, CM_D_ZERO, CM_R_LINEAR, CM_R_ZERO, CM_L_ZERO, CM_COUNT };
+
+// The frequency-independent radial weights of perturb_deformed (src/perturbed.rs:74-108).
+struct CouplingWeights {
+  std::vector<double> trapezoid, te_a, adte_a, te_b, adte_b;
+  CouplingWeights(const DiscreteModel& model, const PerturbedMetric& pm) {
+    const size_t np = model.r_coord.size();
+    trapezoid.assign(np, 0.);
+    trapezoid[0] = 0.5 * (model.r_coord[1] - model.r_coord[0]);
+    trapezoid[np - 1] = 0.5 * (model.r_coord[np - 1] - model.r_coord[np - 2]);
+    for (size_t i = 1; i + 1 < np; ++i) trapezoid[i] = 0.5 * (model.r_coord[i + 1] - model.r_coord[i - 1]);
+    te_a.resize(np); adte_a.resize(np); te_b.resize(np); adte_b.resize(np);
+    for (size_t i = 0; i < np; ++i) {
+      te_a[i] = 3. * pm.alpha[i] + pm.dalpha[i];
+      adte_a[i] = 3. * pm.dalpha[i] + pm.ddalpha[i];
+      te_b[i] = 3. * pm.beta[i] + pm.dbeta[i];
+      adte_b[i] = 3. * pm.dbeta[i] + pm.ddbeta[i];
+    }
+  }
+};
+
+// One (left, right) element of the six matrices: the body of the double loop, src/perturbed.rs:122-263.
+// Throws where the reference asserts finiteness.
+template <class T = double>
+inline void coupling_pair(const DiscreteModel& model, const CouplingWeights& w, const PerturbedMetric& pm,
+                          const ModeToPerturb& l, const ModeToPerturb& r, int64_t m, T (&out)[CM_COUNT]) {
+  const size_t np = model.r_coord.size();
+  const std::vector<double>&trapezoid = w.trapezoid, &te_a = w.te_a, &adte_a = w.adte_a, &te_b = w.te_b, &adte_b = w.adte_b;
+  const T mf = T(double(m));
+  {
+    {
+      const T q2 = T(q_kl2(l.ell, r.ell, m)), q2_hrd = T(q_kl2_hd(l.ell, r.ell, m)), q2_hld = T(q_kl2_hd(r.ell, l.ell, m)),
+              q2_h = T(q_kl2_h(l.ell, r.ell, m));
+      T q_rt_p = T(0.), q_rt_n = T(0.), q_ht_p = T(0.), q_ht_n = T(0.);
+      if (l.ell == r.ell) {
+        const uint64_t n1 = r.ell == 0 ? 0 : r.ell - 1;
+        q_rt_p = T(q_kl1_hd(l.ell, r.ell + 1, m));
+        q_rt_n = T(q_kl1_hd(l.ell, n1, m));
+        q_ht_p = T(-q_kl1_h(l.ell, r.ell + 1, m));
+        q_ht_n = T(-q_kl1_h(l.ell, n1, m));
+      }
+      const T ipr = T(l.ell == r.ell ? 1. : 0.), iph = T(l.ell == r.ell ? double(r.ell * (r.ell + 1)) : 0.);  // :17-23
+      T d_squared = T(0.), d_linear = T(0.), d_zero = T(0.), r_linear = T(0.), r_zero = T(0.), l_zero = T(0.);
+      for (size_t rc = 1; rc < np; ++rc) {  // :148-261
+        const T lxr = T(l.xi_r[rc]), lxh = T(l.xi_h[rc]), lpsi = T(l.psi[rc]), lp = T(l.p[rc]);
+        const T rxr = T(r.xi_r[rc]), rxh = T(r.xi_h[rc]), rtpv = T(r.xi_tp[rc]), rtnv = T(r.xi_tn[rc]), rrho = T(r.rho[rc]);
+        const T rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+        const T rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
+        const T x = T(model.r_coord[rc]), rho = T(model.rho[rc]), rot = T(model.rot[rc]), trap = T(trapezoid[rc]);
+        const T ea = T(pm.alpha[rc]), adea = T(pm.dalpha[rc]), eb = T(pm.beta[rc]), adeb = T(pm.dbeta[rc]);
+        const T tea = T(te_a[rc]), adtea = T(adte_a[rc]), teb = T(te_b[rc]), adteb = T(adte_b[rc]);
+        const T vol = trap * (x * x) * rho;
+        T val = vol * (rr * ipr * (T(1.) + T(2.) * (ea + adea)) + hh * iph * (T(1.) + T(2.) * ea) +
+                       rr * T(2.) * q2 * (eb + adeb) + (rh * q2_hrd + hr * q2_hld + hh * T(2.) * q2_h) * eb);
+        if (!std::isfinite(to_double(val))) throw std::runtime_error("Not finite number (d)");
+        d_squared += val;
+        d_linear += T(2.) * mf * rot * val;
+        d_zero += mf * mf * rot * rot * val;
+        val = vol * T(2.) *
+              (ipr * ((hr + rh) * (T(1.) + T(2.) * ea + adea) + hh * (T(1.) + T(2.) * ea)) +
+               (rh + hr) * q2 * (T(2.) * eb + adeb) + hh * (ipr + T(6.) * q2) * T(2.) * eb);
+        const T val_t = vol * T(2.) * rot * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
+        if (!std::isfinite(to_double(val)) || !std::isfinite(to_double(val_t))) throw std::runtime_error("Not finite number (r)");
+        r_linear += mf * rot * val + val_t;
+        r_zero += mf * rot * (mf * rot * val + val_t);
+        const T sig = T(r.freq) - mf * rot;
+        l_zero += trap * (x * x) *
+                  ((sig * sig) * rho * (ipr * rr + iph * hh) + T(2.) * mf * rot * sig * rho * ipr * (rh + hr + hh) +
+                   lpsi * rrho * tea - rho * lpsi * rxr * adtea / x + lpsi * q2 * rrho * teb -
+                   rho * lpsi * q2 * rxr * adteb / x - lp * rxr * adtea / x - lp * q2 * rxr * adteb / x -
+                   lp * q2_hrd * rxh * teb / x + q2_hrd * rho * lpsi * rxh * teb / x);
+        if (!std::isfinite(to_double(l_zero))) throw std::runtime_error("Not finite number (l)");
+      }
+      out[CM_D_SQUARED] = d_squared; out[CM_D_LINEAR] = d_linear; out[CM_D_ZERO] = d_zero;
+      out[CM_R_LINEAR] = r_linear; out[CM_R_ZERO] = r_zero; out[CM_L_ZERO] = l_zero;
+    }
+  }
+}
+
+// Fills out[CM_COUNT][M*M], each column-major like nalgebra's DMatrix: (left, right) at left + right*M.
+inline void coupling_matrices(const DiscreteModel& model, const std::vector<ModeToPerturb>& modes, int64_t m,
+                              const PerturbedMetric& pm, double* const out[CM_COUNT], int threads = 1) {
+  const size_t M = modes.size();
+  const CouplingWeights w(model, pm);
+  std::vector<std::string> errs(M);
+  parallel_for(M, threads, [&](size_t lm) {
+    try {
+      for (size_t rm = 0; rm < M; ++rm) {
+        double v[CM_COUNT];
+        coupling_pair<double>(model, w, pm, modes[lm], modes[rm], m, v);
+        for (int c = 0; c < CM_COUNT; ++c) out[c][lm + rm * M] = v[c];
+      }
+    } catch (const std::exception& e) { errs[lm] = e.what(); }
+  });
+  for (const std::string& e : errs)
+    if (!e.empty()) throw std::runtime_error(e);
+}
+
+// perturb_structure, src/perturbed.rs:324-460: the deformation of the equilibrium structure by uniform rotation.
+// Used here only to give the coupling-integral tests realistic metric arrays (it stays on the host in the
+// reference).  nalgebra's closed-form 2x2 / 3x3 try_inverse is restated from memory of the
+// crate and pinned by nothing: parity unpinned.
+inline bool inv3(const Mat<double, 3>& a, Mat<double, 3>& o) {
+  const double m11 = a(0, 0), m12 = a(0, 1), m13 = a(0, 2), m21 = a(1, 0), m22 = a(1, 1), m23 = a(1, 2), m31 = a(2, 0),
+               m32 = a(2, 1), m33 = a(2, 2);
+  const double minor_12_23 = m22 * m33 - m32 * m23, minor_11_23 = m21 * m33 - m31 * m23, minor_11_22 = m21 * m32 - m31 * m22;
+  const double det = m11 * minor_12_23 - m12 * minor_11_23 + m13 * minor_11_22;
+  if (det == 0.) return false;
+  o(0, 0) = minor_12_23 / det; o(0, 1) = (m13 * m32 - m33 * m12) / det; o(0, 2) = (m12 * m23 - m22 * m13) / det;
+  o(1, 0) = -minor_11_23 / det; o(1, 1) = (m11 * m33 - m31 * m13) / det; o(1, 2) = (m13 * m21 - m23 * m11) / det;
+  o(2, 0) = minor_11_22 / det; o(2, 1) = (m12 * m31 - m32 * m11) / det; o(2, 2) = (m11 * m22 - m21 * m12) / det;
+  return true;
+}
+inline bool inv2(const Mat<double, 2>& a, Mat<double, 2>& o) {
+  const double det = a(0, 0) * a(1, 1) - a(1, 0) * a(0, 1);
+  if (det == 0.) return false;
+  o(0, 0) = a(1, 1) / det; o(0, 1) = -a(0, 1) / det; o(1, 0) = -a(1, 0) / det; o(1, 1) = a(0, 0) / det;
+  return true;
+}
+inline PerturbedMetric perturb_structure(const DiscreteModel& model, double rot, double* mass_delta_out = nullptr) {
+  const size_t np = model.r_coord.size();
+  const std::vector<double>& x = model.r_coord;
+  std::vector<double> y0x(np, 0.), y0y(np, 0.), y2x(np, 0.), y2y(np, 0.);
+  if (np > 1) { y2x[1] = 1.; y2y[1] = 2.; }
+  auto kcoef = [&](size_t i) {
+    return 4. * M_PI / model.m_coord[i] * model.rho[i] * x[i] * (-model.a_star[i] - model.v[i] / model.gamma1[i]);
+  };
+  for (size_t i = 1; i < np; ++i) {
+    const double delta = x[i] - x[i - 1], x_12 = 0.5 * (x[i] + x[i - 1]);
+    const double k = kcoef(i), k_prev = i == 1 ? 0. : kcoef(i - 1);
+    const double sc = 0.5 * delta / x_12;
+    Mat<double, 3> a0 = Mat<double, 3>::zeros();
+    a0(0, 0) = -1.; a0(0, 1) = 1.; a0(0, 2) = 0.;
+    a0(1, 0) = 0.5 * (x_12 * x_12) * (k + k_prev); a0(1, 1) = -2.; a0(1, 2) = x_12;
+    for (double& e : a0.a) e = sc * e;
+    Mat<double, 3> inv;
+    if (!inv3(sub(Mat<double, 3>::identity(), a0), inv)) throw std::runtime_error("perturb_structure: singular step");
+    const Mat<double, 3> step = mul(inv, add(Mat<double, 3>::identity(), a0));
+    // step[0..2,0..2] * y0[i-1] + step[0..2,2]  (gemv: column axpy, k ascending)
+    const double px = y0x[i - 1], py = y0y[i - 1];
+    y0x[i] = (step(0, 1) * py + step(0, 0) * px) + step(0, 2);
+    y0y[i] = (step(1, 1) * py + step(1, 0) * px) + step(1, 2);
+    if (i != 1) {
+      Mat<double, 2> a2;
+      a2(0, 0) = -1.; a2(0, 1) = 1.; a2(1, 0) = 6. + 0.5 * (x_12 * x_12) * (k + k_prev); a2(1, 1) = -2.;
+      for (double& e : a2.a) e = sc * e;
+      Mat<double, 2> inv_2;
+      if (!inv2(sub(Mat<double, 2>::identity(), a2), inv_2)) throw std::runtime_error("perturb_structure: singular step");
+      const Mat<double, 2> st2 = mul(inv_2, add(Mat<double, 2>::identity(), a2));
+      const double qx = y2x[i - 1], qy = y2y[i - 1];
+      y2x[i] = st2(0, 1) * qy + st2(0, 0) * qx;
+      y2y[i] = st2(1, 1) * qy + st2(1, 0) * qx;
+    }
+  }
+  const double a2c = -5. / 6. / (3. * y2x[np - 1] + y2y[np - 1]);
+  PerturbedMetric pm;
+  for (auto* v : {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta}) v->assign(np, 0.);
+  std::vector<double> trapezoid(np, 0.);
+  trapezoid[0] = 0.5 * (x[1] - x[0]);
+  trapezoid[np - 1] = 0.5 * (x[np - 1] - x[np - 2]);
+  for (size_t i = 1; i + 1 < np; ++i) trapezoid[i] = 0.5 * (x[i + 1] - x[i - 1]);
+  double mass_delta = 0.;
+  const double rot2 = rot * rot;
+  for (size_t i = 1; i < np; ++i) {
+    const double dln = -model.a_star[i] - model.v[i] / model.gamma1[i];
+    const double k = 4. * M_PI / model.m_coord[i] * model.rho[i] * x[i] * dln;
+    const double u = model.u[i];
+    auto fill = [&](double psi, double dpsi, double ddpsi, double& f, double& df, double& ddf) {
+      f = 2. * x[i] / model.m_coord[i] * psi * rot2;
+      df = f * (1. - u + x[i] * dpsi / psi);
+      ddf = df * (1. - u + x[i] * dpsi / psi) +
+            f * (-3. * u - u * dln + u * u + x[i] * dpsi / psi - (x[i] * dpsi / psi) * (x[i] * dpsi / psi) +
+                 (x[i] * x[i]) * ddpsi / psi);
+    };
+    fill(y0x[i] * x[i], y0y[i], ((x[i] * x[i]) * k * y0x[i] - 2. * y0y[i]) / x[i] + 1., pm.alpha[i], pm.dalpha[i], pm.ddalpha[i]);
+    fill(y2x[i] * x[i] * a2c, y2y[i] * a2c, ((6. + (x[i] * x[i]) * k) * y2x[i] - 2. * y2y[i]) / x[i] * a2c, pm.beta[i], pm.dbeta[i],
+         pm.ddbeta[i]);
+    mass_delta += trapezoid[i] * model.rho[i] * (x[i] * x[i]) * (3. * pm.alpha[i] + pm.dalpha[i]);
+  }
+  if (mass_delta_out) *mass_delta_out = mass_delta * (4. * M_PI);
+  return pm;
 }
 
 }  // namespace storm_ref

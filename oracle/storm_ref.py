@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libstorm_ref.so")
 
 POST_FIELDS = ["y1", "y2", "y3", "y4", "xi_r", "xi_h", "xi_tn", "xi_tp", "psi", "dpsi", "rho", "p", "chi"]
+METRIC_FIELDS = ["alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta"]
+COUPLING_MATRICES = ["d_squared", "d_linear", "d_zero", "r_linear", "r_zero", "l_zero"]
 SCHEMES = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magnus6", "magnus8"]
 
 
@@ -86,6 +88,9 @@ def lib():
         L.sref_postprocess_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, C.c_size_t, _dp, _dp,
                                              C.POINTER(C.c_int64), _dp, C.c_size_t, C.POINTER(C.c_uint64), C.c_int]
         L.sref_gaunt.argtypes = [C.c_uint64, C.c_int64, _dp]
+        L.sref_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), _dp, _dp, C.c_int64,
+                                             C.POINTER(_dp), _dp, C.POINTER(C.c_uint64), C.c_int]
+        L.sref_perturb_structure.argtypes = [C.c_void_p, C.c_double, C.POINTER(_dp), _dp]
         L.sref_powi.restype = C.c_double
         L.sref_powi.argtypes = [C.c_double, C.c_int]
         L.sref_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
@@ -194,6 +199,32 @@ class Model:
                                             nn.ctypes.data_as(C.POINTER(C.c_uint64)), threads))
         return dict(fields=fields, ids=ids, n_nodes=nn.astype(np.int64),
                     nodes=[nodes[k, :min(int(nn[k]), cap)].copy() for k in range(f.size)])
+
+    def perturb_structure(self, rot):
+        """perturb_structure (src/perturbed.rs:324-460): dict of alpha, dalpha, ddalpha, beta, dbeta, ddbeta, mass_delta."""
+        arrs = [np.zeros(len(self)) for _ in METRIC_FIELDS]
+        ptrs = (_dp * 6)(*[_p(a) for a in arrs])
+        md = np.zeros(1)
+        _check(lib().sref_perturb_structure(self._h, rot, ptrs, _p(md)))
+        out = dict(zip(METRIC_FIELDS, arrs))
+        out["mass_delta"] = float(md[0])
+        return out
+
+    def coupling_matrices(self, ells, freqs, fields, m, metric, threads=1):
+        """The six M x M matrices of perturb_deformed (src/perturbed.rs:110-263) for modes given by their
+        post-processing fields [M,13,n_pts].  Returns (dict name -> [M,M] array indexed [left,right], flops per term)."""
+        ells = np.ascontiguousarray(ells, dtype=np.uint64)
+        f = _f64(freqs)
+        fl = _f64(fields)
+        M = f.size
+        assert fl.shape == (M, len(POST_FIELDS), len(self))
+        arrs = [_f64(metric[k]) for k in METRIC_FIELDS]
+        ptrs = (_dp * 6)(*[_p(a) for a in arrs])
+        out = np.zeros((len(COUPLING_MATRICES), M * M))
+        flops = C.c_uint64(0)
+        _check(lib().sref_coupling_matrices(self._h, M, ells.ctypes.data_as(C.POINTER(C.c_uint64)), _p(f), _p(fl), m, ptrs,
+                                            _p(out), C.byref(flops), threads))
+        return {k: out[i].reshape(M, M).T.copy() for i, k in enumerate(COUPLING_MATRICES)}, int(flops.value)
 
     def __del__(self):
         try:

@@ -216,6 +216,46 @@ int sref_gaunt(uint64_t ell, int64_t mm, double* out4) {  // {q_hd_n, q_hd_p, q_
 }
 double sref_powi(double a, int b) { return powi(a, b); }
 
+// perturb_deformed's six coupling matrices (src/perturbed.rs:110-263).  fields is [M][13][n_pts] in PostField order
+// (the layout sref_postprocess_batch / storm_postprocess_batch write), metric6 = {alpha, dalpha, ddalpha, beta,
+// dbeta, ddbeta} each [n_pts]; out is [6][M*M] column-major per matrix; flops_out (may be NULL) receives the exact
+// add+mul+div count of ONE (left, right, point) term, measured with the op-counting scalar.
+int sref_coupling_matrices(void* m, size_t M, const uint64_t* ells, const double* freqs, const double* fields, int64_t mm,
+                           const double* const* metric6, double* out, uint64_t* flops_out, int threads) {
+  const DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
+  const size_t np = d.size();
+  return guarded([&] {
+    PerturbedMetric pm;
+    std::vector<double>* dst[6] = {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta};
+    for (int k = 0; k < 6; ++k) dst[k]->assign(metric6[k], metric6[k] + np);
+    std::vector<ModeToPerturb> modes(M);
+    for (size_t k = 0; k < M; ++k) {
+      const double* f = fields + k * PF_COUNT * np;
+      modes[k] = ModeToPerturb{ells[k], freqs[k], f + PF_XI_R * np, f + PF_XI_H * np, f + PF_XI_TN * np, f + PF_XI_TP * np,
+                               f + PF_PSI * np, f + PF_RHO * np, f + PF_P * np};
+    }
+    double* o[CM_COUNT];
+    for (int c = 0; c < CM_COUNT; ++c) o[c] = out + size_t(c) * M * M;
+    coupling_matrices(d, modes, mm, pm, o, threads);  // rows of the (left, right) loop are independent
+    if (flops_out && M) {
+      Counted::reset();
+      Counted v[CM_COUNT];
+      coupling_pair<Counted>(d, CouplingWeights(d, pm), pm, modes[0], modes[0], mm, v);
+      *flops_out = Counted::total() / (np - 1);
+    }
+  });
+}
+
+// perturb_structure (src/perturbed.rs:324-460): out6 = {alpha, dalpha, ddalpha, beta, dbeta, ddbeta}, each [n_pts].
+int sref_perturb_structure(void* m, double rot, double* const* out6, double* mass_delta) {
+  const DiscreteModel& d = static_cast<ModelHandle*>(m)->discrete;
+  return guarded([&] {
+    PerturbedMetric pm = perturb_structure(d, rot, mass_delta);
+    const std::vector<double>* src[6] = {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta};
+    for (int k = 0; k < 6; ++k) std::copy(src[k]->begin(), src[k]->end(), out6[k]);
+  });
+}
+
 // Matrix exponential known-answer entry (N = 3 or 4), column-major in place.
 int sref_exp(int n, double* a) {
   return guarded([&] {

@@ -5,4 +5,5 @@ gfx950, see storm_amd/csrc and include/storm_hip.h).  This package is only the t
 ctypes binding used by the tests and the benchmark; there is no CPU fallback.
 """
 from .ffi import (HipSolver, HipPostproc, StormError, Bracket, SCHEMES, POST_FIELDS, MODEL_FIELDS,  # noqa: F401
+                  METRIC_FIELDS, COUPLING_MATRICES,
                   lib_path, load_library, relative_to_ulp)

@@ -200,6 +200,34 @@ int storm_host_modes(void* p, void* solver, const double* roots, size_t n, int w
   });
 }
 
+// perturb_deformed's integrals through the mirror: fields [n][13][n_pts], metric6 = alpha, dalpha, ddalpha, beta, dbeta,
+// ddbeta; out [6][n*n] column-major per matrix.
+int storm_host_coupling_matrices(void* p, size_t n, const uint64_t* ells, const double* freqs, const double* fields,
+                                 int64_t mm, const double* const* metric6, double* out) {
+  PostProcessor* pp = static_cast<PostProcessor*>(p);
+  return guarded([&] {
+    const size_t np = pp->len();
+    std::vector<Rotating1DPostprocessing> posts(n);
+    std::vector<ModeToPerturb> modes(n);
+    for (size_t k = 0; k < n; ++k) {
+      Rotating1DPostprocessing& r = posts[k];
+      std::vector<double>* dst[STORM_POST_FIELDS] = {&r.y1, &r.y2, &r.y3, &r.y4, &r.xi_r, &r.xi_h, &r.xi_tn, &r.xi_tp,
+                                                     &r.psi, &r.dpsi, &r.rho, &r.p, &r.chi};
+      for (int f = 0; f < STORM_POST_FIELDS; ++f) {
+        const double* src = fields + (k * STORM_POST_FIELDS + f) * np;
+        dst[f]->assign(src, src + np);
+      }
+      modes[k] = ModeToPerturb{ells[k], freqs[k], &posts[k]};
+    }
+    PerturbedMetric pm;
+    std::vector<double>* md[6] = {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta};
+    for (int k = 0; k < 6; ++k) md[k]->assign(metric6[k], metric6[k] + np);
+    const CouplingMatrices c = pp->coupling_matrices(modes, mm, pm);
+    const std::vector<double>* src[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
+    for (int k = 0; k < STORM_COUPLING_MATRICES; ++k) std::memcpy(out + size_t(k) * n * n, src[k]->data(), n * n * sizeof(double));
+  });
+}
+
 double storm_host_polytrope0_exact(double gamma1, uint64_t ell, int64_t radial_order) {
   return Polytrope0(gamma1).exact(ell, radial_order);
 }

@@ -421,6 +421,38 @@ std::vector<Rotating1DPostprocessing> PostProcessor::modes(const ErasedSolver& s
   return unpack(n, fields, ids, nodes, np);
 }
 
+CouplingMatrices PostProcessor::coupling_matrices(const std::vector<ModeToPerturb>& modes, int64_t m,
+                                                  const PerturbedMetric& metric) const {
+  const size_t n = modes.size(), np = x_.size();
+  CouplingMatrices out;
+  out.n = n;
+  if (n == 0) return out;
+  std::vector<uint64_t> ell(n);
+  std::vector<double> freq(n), fields(n * STORM_POST_FIELDS * np);
+  for (size_t k = 0; k < n; ++k) {
+    const Rotating1DPostprocessing& r = *modes[k].post_processing;
+    const std::vector<double>* src[STORM_POST_FIELDS] = {&r.y1, &r.y2, &r.y3, &r.y4, &r.xi_r, &r.xi_h, &r.xi_tn, &r.xi_tp,
+                                                         &r.psi, &r.dpsi, &r.rho, &r.p, &r.chi};
+    for (int f = 0; f < STORM_POST_FIELDS; ++f) {
+      if (src[f]->size() != np) throw std::runtime_error("coupling_matrices: a mode was post-processed on another grid");
+      std::memcpy(fields.data() + (k * STORM_POST_FIELDS + f) * np, src[f]->data(), np * sizeof(double));
+    }
+    ell[k] = modes[k].ell;
+    freq[k] = modes[k].freq;
+  }
+  for (const std::vector<double>* a : {&metric.alpha, &metric.dalpha, &metric.ddalpha, &metric.beta, &metric.dbeta, &metric.ddbeta})
+    if (a->size() != np) throw std::runtime_error("coupling_matrices: the metric lives on another grid");
+  const storm_metric_desc md{metric.alpha.data(), metric.dalpha.data(), metric.ddalpha.data(),
+                             metric.beta.data(), metric.dbeta.data(), metric.ddbeta.data()};
+  std::vector<double> flat(size_t(STORM_COUPLING_MATRICES) * n * n);
+  const int rc = storm_coupling_matrices(h_, n, ell.data(), freq.data(), fields.data(), m, &md, flat.data());
+  if (rc != STORM_OK) raise_abi("storm_coupling_matrices", rc);
+  std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&out.d_squared, &out.d_linear, &out.d_zero,
+                                                       &out.r_linear, &out.r_zero, &out.l_zero};
+  for (int c = 0; c < STORM_COUPLING_MATRICES; ++c) dst[c]->assign(flat.begin() + size_t(c) * n * n, flat.begin() + size_t(c + 1) * n * n);
+  return out;
+}
+
 Rotating1DPostprocessing Rotating1DPostprocessing::make(double freq, const std::vector<double>& eigenvector, uint64_t ell,
                                                         int64_t m, const DiscreteModel& model) {
   if (eigenvector.size() % 4 != 0) throw std::runtime_error("eigenvector length is not a multiple of 4");

@@ -14,6 +14,7 @@
 //   Model::grid, linspace, rev_linspace, StormState::scan   main.rs:661-679,793-838,1232-1238
 //   Rotating1DPostprocessing::new     postprocessing.rs:58   Rotating1DPostprocessing::make / post_process
 //   StormState::post_process          main.rs:878-899   post_process
+//   perturb_deformed (integrals)      perturbed.rs:56-263   PostProcessor::coupling_matrices -> ModeCoupling{d,r,l,...}
 //
 // The Rust host does exactly this work before it reaches the FFI seam: interpolate
 // the model at the collocation abscissae (DiscretizedSystemImpl::new, discretized.rs:81-123) and
@@ -164,6 +165,24 @@ struct Rotating1DPostprocessing {
                                        const DiscreteModel& model);
 };
 
+struct PerturbedMetric {  // model.rs:104-123
+  std::vector<double> alpha, dalpha, ddalpha, beta, dbeta, ddbeta;
+  double rot = 0., mass_delta = 0.;
+};
+struct ModeToPerturb {  // perturbed.rs:26-33
+  uint64_t ell;
+  double freq;
+  const Rotating1DPostprocessing* post_processing;
+};
+// The six matrices perturb_deformed integrates (perturbed.rs:110-120), each n x n column-major like DMatrix
+// ((left, right) at left + right*n).  ModeCoupling's d, r, l are d_squared, r_linear, l_zero (perturbed.rs:313-320);
+// the generalised eigenproblem assembled from all six (perturbed.rs:265-311, linalg/qz.rs) is the caller's.
+struct CouplingMatrices {
+  size_t n = 0;
+  std::vector<double> d_squared, d_linear, d_zero, r_linear, r_zero, l_zero;
+  double at(const std::vector<double>& mat, size_t left, size_t right) const { return mat[left + right * n]; }
+};
+
 // The model arrays of the post-processing resident on the device (storm_postproc).
 class PostProcessor {
  public:
@@ -176,6 +195,8 @@ class PostProcessor {
   // Eigenvectors and post-processing in one device pass (storm_modes_batch); mode ids only unless want_fields.
   std::vector<Rotating1DPostprocessing> modes(const ErasedSolver& solver, const std::vector<double>& roots,
                                               bool want_fields) const;
+  // The integrals of perturb_deformed(model, modes, m, metric) (perturbed.rs:56-263).
+  CouplingMatrices coupling_matrices(const std::vector<ModeToPerturb>& modes, int64_t m, const PerturbedMetric& metric) const;
   size_t len() const { return x_.size(); }
   storm_postproc* handle() const { return h_; }
 

@@ -236,6 +236,76 @@ __global__ __launch_bounds__(64) void post_modes_kernel(PostModelDev md, PostPar
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Mode-coupling integrals (reference src/perturbed.rs:110-263): six M x M matrices, each element a sum over the
+// radial grid of ~150 flops of products of the left and right modes' post-processing fields.
+// Lane = one (left, right) pair, wave = 8 x 8 tile of pairs; every lane walks the grid in index order with its
+// six accumulators (the reference's `+=` loop: a sequential sum), so results are bit-identical.  The per-point
+// weights are wave-uniform (scalar loads); the 4 left / 5 right field values come from 8 + 8 distinct rows per
+// wave.  FP64 VALU bound (148 flops per 72 B of fields that hit L1/L2: every row is shared by 8 lanes and by
+// M/8 waves).  No MFMA: the contraction could be phrased as ~20 weighted GEMMs, but MFMA accumulates with fused
+// multiply-adds in its own order and would change the last bits of every element; FP64 MFMA has the same peak as
+// the FP64 vector pipe on MI355X, so the only cost of staying on the VALU is the un-fused mul/add split.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void coupling_kernel(CouplingArgs a) {
+  const int lane = threadIdx.x;
+  const size_t M = a.n_modes, np = a.n_pts;
+  const size_t lm_raw = (size_t)blockIdx.x * 8 + (lane >> 3), rm_raw = (size_t)blockIdx.y * 8 + (lane & 7);
+  const bool live = lm_raw < M && rm_raw < M;
+  const size_t lm = lm_raw < M ? lm_raw : M - 1, rm = rm_raw < M ? rm_raw : M - 1;
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lm] * a.n_ell + a.ell_index[rm]) * kCouplingConsts;
+  const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
+  const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
+  const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
+  const double k6 = ipr + 6.0 * q2;
+  const double rfreq = a.freq[rm];
+  const double* __restrict__ lf = a.fields + lm * kPostFields * np;
+  const double* __restrict__ rf = a.fields + rm * kPostFields * np;
+  const double* __restrict__ l_xr = lf + XI_R * np; const double* __restrict__ l_xh = lf + XI_H * np;
+  const double* __restrict__ l_psi = lf + PSI * np; const double* __restrict__ l_p = lf + PRS * np;
+  const double* __restrict__ r_xr = rf + XI_R * np; const double* __restrict__ r_xh = rf + XI_H * np;
+  const double* __restrict__ r_tp = rf + XI_TP * np; const double* __restrict__ r_tn = rf + XI_TN * np;
+  const double* __restrict__ r_rho = rf + RHO * np;
+  const double* __restrict__ w = a.weights;
+  double d_squared = 0.0, d_linear = 0.0, d_zero = 0.0, r_linear = 0.0, r_zero = 0.0, l_zero = 0.0;
+  bool finite = true;
+#pragma unroll 2
+  for (size_t rc = 1; rc < np; ++rc) {  // src/perturbed.rs:148-261
+    const double* __restrict__ u = w + rc * kCouplingWeights;  // wave-uniform
+    const double lxr = l_xr[rc], lxh = l_xh[rc], lpsi = l_psi[rc], lp = l_p[rc];
+    const double rxr = r_xr[rc], rxh = r_xh[rc], rtpv = r_tp[rc], rtnv = r_tn[rc], rrho = r_rho[rc];
+    const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+    const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
+    const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
+    double val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
+                              (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+    finite = finite && isfinite(val);
+    d_squared += val;
+    d_linear += u[CW_C1] * val;
+    d_zero += u[CW_C2] * val;
+    val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+    const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
+    finite = finite && isfinite(val) && isfinite(val_t);
+    const double mrot = u[CW_MROT];
+    r_linear += mrot * val + val_t;
+    r_zero += mrot * (mrot * val + val_t);
+    const double sig = rfreq - mrot;
+    const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
+    l_zero += u[CW_TR2] *
+              ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) + lpsi * rrho * tea -
+               rho * lpsi * rxr * adtea / x + lpsi * q2 * rrho * teb - rho * lpsi * q2 * rxr * adteb / x - lp * rxr * adtea / x -
+               lp * q2 * rxr * adteb / x - lp * q2_hrd * rxh * teb / x + q2_hrd * rho * lpsi * rxh * teb / x);
+    finite = finite && isfinite(l_zero);
+  }
+  if (live) {
+    const size_t at = lm + rm * M, mm = M * M;
+    a.out[0 * mm + at] = d_squared; a.out[1 * mm + at] = d_linear; a.out[2 * mm + at] = d_zero;
+    a.out[3 * mm + at] = r_linear; a.out[4 * mm + at] = r_zero; a.out[5 * mm + at] = l_zero;
+    if (!finite) atomicOr(a.flags, 1);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_postprocess(const PostArgs& a) {
@@ -253,6 +323,15 @@ hipError_t launch_postprocess(const PostArgs& a) {
     e = hipGetLastError();
   }
   return e;
+}
+
+hipError_t launch_coupling(const CouplingArgs& a) {
+  if (a.n_modes == 0) return hipSuccess;
+  if (a.n_pts < 2) return hipErrorInvalidValue;
+  const unsigned tiles = (unsigned)((a.n_modes + 7) / 8);
+  if (tiles > 65535) return hipErrorInvalidValue;
+  coupling_kernel<<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
+  return hipGetLastError();
 }
 
 }  // namespace storm

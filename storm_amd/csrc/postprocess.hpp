@@ -45,3 +45,44 @@ struct PostArgs {
 hipError_t launch_postprocess(const PostArgs& args);
 
 }  // namespace storm
+
+// ---- mode-coupling integrals of the deformed star: perturb_deformed, reference src/perturbed.rs:110-263 ----
+namespace storm {
+
+constexpr int kCouplingMatrices = 6;  // d_squared, d_linear, d_zero, r_linear, r_zero, l_zero
+// Per-point weights, identical for every mode pair (evaluated once on the host, same expressions):
+enum CouplingWeight : int {
+  CW_TR2 = 0,   // trapezoid * r^2
+  CW_VOL,       // trapezoid * r^2 * rho
+  CW_VOL2,      // vol * 2
+  CW_VOL2ROT,   // vol * 2 * rot
+  CW_C1,        // 2 * m * rot
+  CW_C2,        // m * m * rot * rot
+  CW_MROT,      // m * rot
+  CW_RHO, CW_X,
+  CW_U1,        // 1 + 2 (eps_a + a d eps_a)
+  CW_U2,        // 1 + 2 eps_a
+  CW_U3,        // eps_b + a d eps_b
+  CW_U4,        // 1 + 2 eps_a + a d eps_a
+  CW_U5,        // 2 eps_b + a d eps_b
+  CW_EB, CW_TEA, CW_ADTEA, CW_TEB, CW_ADTEB,
+  kCouplingWeights = 20  // padded: rows of 160 B
+};
+// Per-(ell_left, ell_right) Gaunt factors (src/perturbed.rs:126-146).
+enum CouplingConst : int { CQ_Q2 = 0, CQ_Q2_HRD, CQ_Q2_HLD, CQ_Q2_H, CQ_RT_P, CQ_RT_N, CQ_HT_P, CQ_HT_N, CQ_IPR, CQ_IPH, kCouplingConsts };
+
+struct CouplingArgs {
+  size_t n_pts, n_modes;
+  const double* fields;    // device [n_modes][13][n_pts], post-processing layout
+  const double* freq;      // device [n_modes]
+  const int* ell_index;    // device [n_modes], index into the distinct-ell list
+  const double* consts;    // device [n_ell][n_ell][kCouplingConsts]
+  int n_ell;
+  const double* weights;   // device [n_pts][kCouplingWeights]
+  double* out;             // device [kCouplingMatrices][n_modes*n_modes], (left, right) at left + right*n_modes
+  int* flags;              // device; bit 0 set if a term was not finite (the reference asserts)
+  hipStream_t stream;
+};
+hipError_t launch_coupling(const CouplingArgs& args);
+
+}  // namespace storm

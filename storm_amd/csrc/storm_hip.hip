@@ -129,9 +129,13 @@ struct storm_postproc {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_vec, d_terms, d_scale, d_fields, d_nodes;
   DevBuf<long long> d_ids;
+  DevBuf<double> d_weights, d_consts, d_out;  // coupling integrals
+  DevBuf<int> d_ell_index, d_cflags;
+  std::vector<double> h_r, h_rho, h_rot, h_trap;  // host copies of the planes the coupling weights are built from
   PinnedBuf h_stage;
   std::vector<long long> h_ids;
   size_t bytes_max = size_t(1) << 30;  // cap of the per-batch scratch (modes are processed in chunks)
+  double last_coupling_ms = 0.0;       // HIP-event duration of the last coupling kernel
   std::mutex mu;
 };
 
@@ -452,6 +456,22 @@ double gaunt_q_kl1_hd(uint64_t k, uint64_t l, int64_t m) {
   const double lk = double(k * (k + 1)), ll = double(l * (l + 1));
   return gaunt_q_kl1(k, l, m) * ((ll - lk) / 2. + 1.);
 }
+double gaunt_q_kl2(uint64_t k, uint64_t l, int64_t m) {  // src/gaunt.rs:19-30
+  double v;
+  if (k == l) { const double a = gaunt_beta(k + 1, m), b = gaunt_beta(k, m); v = a * a + b * b - 1. / 3.; }
+  else if (k == l + 2) v = gaunt_beta(k, m) * gaunt_beta(l + 1, m);
+  else if (k + 2 == l) v = gaunt_beta(k + 1, m) * gaunt_beta(l, m);
+  else v = 0.;
+  return (3. / 2.) * v;
+}
+double gaunt_q_kl2_h(uint64_t k, uint64_t l, int64_t m) {  // src/gaunt.rs:39-44
+  const double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return gaunt_q_kl2(k, l, m) * ((lk + ll) / 2. - 3.);
+}
+double gaunt_q_kl2_hd(uint64_t k, uint64_t l, int64_t m) {  // src/gaunt.rs:53-58
+  const double lk = double(k * (k + 1)), ll = double(l * (l + 1));
+  return gaunt_q_kl2(k, l, m) * ((ll - lk) / 2. + 3.);
+}
 PostParams post_params(uint64_t ell, int64_t m) {  // src/postprocessing.rs:85-95
   if (ell > 1000000) fail(STORM_ERR_INVALID_ARGUMENT, "ell does not fit (the reference converts it to i32)");
   const uint64_t n1 = ell == 0 ? 0 : ell - 1;
@@ -759,6 +779,10 @@ int storm_postproc_create(const storm_model_desc* d, storm_postproc** out) {
     hip_check(hipStreamSynchronize(p->stream), "model upload");
     p->model.tab = p->tab.p;
     p->model.n_pts = np;
+    p->h_r.assign(d->r_coord, d->r_coord + np);
+    p->h_rho.assign(d->rho, d->rho + np);
+    p->h_rot.assign(d->rot, d->rot + np);
+    p->h_trap.assign(trap, trap + np);
     *out = p.release();
   });
 }
@@ -771,6 +795,7 @@ void storm_postproc_destroy(storm_postproc* p) {
   if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
   p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
   p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
+  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release();
   (void)hipSetDevice(prev);
   delete p;
 }
@@ -797,6 +822,112 @@ int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const do
     }
   });
 }
+
+int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, const double* freq, const double* fields,
+                            int64_t m, const storm_metric_desc* metric, double* out) {
+  return guarded([&] {
+    if (!p || (n && (!ell || !freq || !fields || !metric || !out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    const double* ms[6] = {metric->alpha, metric->dalpha, metric->ddalpha, metric->beta, metric->dbeta, metric->ddbeta};
+    for (const double* q : ms)
+      if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null metric array");
+    if (n > 8 * size_t(65535)) fail(STORM_ERR_INVALID_ARGUMENT, "too many modes");
+    std::lock_guard<std::mutex> lock(p->mu);
+    DeviceGuard g(p->device);
+    const size_t np = p->model.n_pts;
+    // per-point weights: the mode-independent sub-expressions of src/perturbed.rs:88-108,157-252
+    std::vector<double> w(np * kCouplingWeights, 0.0);
+    const double mf = double(m);
+    for (size_t i = 0; i < np; ++i) {
+      double* u = w.data() + i * kCouplingWeights;
+      const double x = p->h_r[i], rho = p->h_rho[i], rot = p->h_rot[i];
+      const double ea = metric->alpha[i], adea = metric->dalpha[i], eb = metric->beta[i], adeb = metric->dbeta[i];
+      u[CW_TR2] = p->h_trap[i] * (x * x);
+      u[CW_VOL] = p->h_trap[i] * (x * x) * rho;
+      u[CW_VOL2] = u[CW_VOL] * 2.;
+      u[CW_VOL2ROT] = u[CW_VOL] * 2. * rot;
+      u[CW_C1] = 2. * mf * rot;
+      u[CW_C2] = mf * mf * rot * rot;
+      u[CW_MROT] = mf * rot;
+      u[CW_RHO] = rho; u[CW_X] = x;
+      u[CW_U1] = 1. + 2. * (ea + adea);
+      u[CW_U2] = 1. + 2. * ea;
+      u[CW_U3] = eb + adeb;
+      u[CW_U4] = 1. + 2. * ea + adea;
+      u[CW_U5] = 2. * eb + adeb;
+      u[CW_EB] = eb;
+      u[CW_TEA] = 3. * ea + adea;
+      u[CW_ADTEA] = 3. * metric->dalpha[i] + metric->ddalpha[i];
+      u[CW_TEB] = 3. * eb + adeb;
+      u[CW_ADTEB] = 3. * metric->dbeta[i] + metric->ddbeta[i];
+    }
+    // Gaunt factors per pair of distinct degrees (src/perturbed.rs:126-146)
+    std::vector<uint64_t> ells;
+    std::vector<int> ell_index(n);
+    for (size_t k = 0; k < n; ++k) {
+      size_t at = 0;
+      while (at < ells.size() && ells[at] != ell[k]) ++at;
+      if (at == ells.size()) ells.push_back(ell[k]);
+      ell_index[k] = int(at);
+    }
+    const size_t ne = ells.size();
+    std::vector<double> consts(ne * ne * kCouplingConsts, 0.0);
+    for (size_t a = 0; a < ne; ++a)
+      for (size_t b = 0; b < ne; ++b) {
+        double* q = consts.data() + (a * ne + b) * kCouplingConsts;
+        const uint64_t le = ells[a], re = ells[b];
+        q[CQ_Q2] = gaunt_q_kl2(le, re, m);
+        q[CQ_Q2_HRD] = gaunt_q_kl2_hd(le, re, m);
+        q[CQ_Q2_HLD] = gaunt_q_kl2_hd(re, le, m);
+        q[CQ_Q2_H] = gaunt_q_kl2_h(le, re, m);
+        if (le == re) {
+          const uint64_t n1 = re == 0 ? 0 : re - 1;
+          q[CQ_RT_P] = gaunt_q_kl1_hd(le, re + 1, m);
+          q[CQ_RT_N] = gaunt_q_kl1_hd(le, n1, m);
+          q[CQ_HT_P] = -gaunt_q_kl1_h(le, re + 1, m);
+          q[CQ_HT_N] = -gaunt_q_kl1_h(le, n1, m);
+          q[CQ_IPR] = 1.;
+          q[CQ_IPH] = double(re * (re + 1));
+        }
+      }
+    const size_t nf = n * kPostFields * np;
+    p->d_fields.reserve(nf);
+    p->d_freq.reserve(n);
+    p->d_weights.reserve(w.size());
+    p->d_consts.reserve(consts.size());
+    p->d_ell_index.reserve(n);
+    p->d_out.reserve(size_t(kCouplingMatrices) * n * n);
+    p->d_cflags.reserve(1);
+    hipStream_t st = p->stream;
+    hip_check(hipMemcpyAsync(p->d_fields.p, fields, nf * sizeof(double), hipMemcpyHostToDevice, st), "fields H2D");
+    hip_check(hipMemcpyAsync(p->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+    hip_check(hipMemcpyAsync(p->d_weights.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st), "weights H2D");
+    hip_check(hipMemcpyAsync(p->d_consts.p, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice, st), "consts H2D");
+    hip_check(hipMemcpyAsync(p->d_ell_index.p, ell_index.data(), n * sizeof(int), hipMemcpyHostToDevice, st), "ell H2D");
+    hip_check(hipMemsetAsync(p->d_cflags.p, 0, sizeof(int), st), "flags memset");
+    CouplingArgs a;
+    a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
+    a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
+    a.stream = st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hip_check(hipEventCreate(&e0), "hipEventCreate");
+    hip_check(hipEventCreate(&e1), "hipEventCreate");
+    hip_check(hipEventRecord(e0, st), "hipEventRecord");
+    hip_check(launch_coupling(a), "coupling launch");
+    hip_check(hipEventRecord(e1, st), "hipEventRecord");
+    int flags = 0;
+    hip_check(hipMemcpyAsync(out, p->d_out.p, size_t(kCouplingMatrices) * n * n * sizeof(double), hipMemcpyDeviceToHost, st), "out D2H");
+    hip_check(hipMemcpyAsync(&flags, p->d_cflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+    hip_check(hipStreamSynchronize(st), "coupling");
+    float kernel_ms = 0.f;
+    (void)hipEventElapsedTime(&kernel_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    p->last_coupling_ms = double(kernel_ms);
+    if (flags & 1) fail(STORM_ERR_NON_FINITE, "Not finite number in a coupling integral (the reference asserts, src/perturbed.rs:165-260)");
+  });
+}
+
+double storm_postproc_last_kernel_ms(const storm_postproc* p) { return p ? p->last_coupling_ms : 0.0; }
 
 int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, size_t n, double* det_out, double* vec_out,
                       double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {

