@@ -12,6 +12,7 @@
 //   post_fields   lane = (mode, point): all 13 fields recomputed and stored scaled          (136 B/pt/mode)
 // Recomputing the point in post_fields costs ~80 flops and saves storing + re-reading 13 unscaled fields.
 #include "postprocess.hpp"
+#include "shared_div.hpp"
 
 #define PDEV __device__ __forceinline__
 
@@ -239,64 +240,112 @@ __global__ __launch_bounds__(64) void post_modes_kernel(PostModelDev md, PostPar
 
 // ---------------------------------------------------------------------------------------
 // Mode-coupling integrals (reference src/perturbed.rs:110-263): six M x M matrices, each element a sum over the
-// radial grid of ~150 flops of products of the left and right modes' post-processing fields.
+// radial grid of 148 flops of products of the left and right modes' post-processing fields.
 // Lane = one (left, right) pair, wave = 8 x 8 tile of pairs; every lane walks the grid in index order with its
-// six accumulators (the reference's `+=` loop: a sequential sum), so results are bit-identical.  The per-point
-// weights are wave-uniform (scalar loads); the 4 left / 5 right field values come from 8 + 8 distinct rows per
-// wave.  FP64 VALU bound (148 flops per 72 B of fields that hit L1/L2: every row is shared by 8 lanes and by
-// M/8 waves).  No MFMA: the contraction could be phrased as ~20 weighted GEMMs, but MFMA accumulates with fused
-// multiply-adds in its own order and would change the last bits of every element; FP64 MFMA has the same peak as
-// the FP64 vector pipe on MI355X, so the only cost of staying on the VALU is the un-fused mul/add split.
+// six accumulators (the reference's `+=` loop: a sequential sum), so results are bit-identical.
+// Staging: per chunk of 8 grid points the wave needs 4 fields of its 8 left modes, 5 of its 8 right modes
+// and the 8 x 20 mode-independent weights; they are copied global -> LDS by LDS-DMA
+// (global_load_lds_dword: no VGPRs, any 4-byte alignment) one chunk ahead of the arithmetic, so the serial walk
+// never waits for memory.  FP64 VALU bound (148 flops per (pair, point); fields are read once per 8 x 8 tile).
+// No MFMA: the contraction could be phrased as ~20 weighted GEMMs, but MFMA accumulates with fused multiply-adds
+// in its own order and would change the last bits of every element; FP64 MFMA has the same peak as the FP64
+// vector pipe on MI355X, so the only cost of staying on the VALU is the un-fused mul/add split.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void coupling_kernel(CouplingArgs a) {
+constexpr int kCpChunk = 8;                                      // grid points per staged chunk
+constexpr int kCpPlane = kCpChunk * 8;                           // doubles: [point][mode of the tile]
+constexpr int kCpFieldTile = 9 * kCpPlane;                       // 4 left + 5 right planes
+constexpr int kCpTile = kCpFieldTile + kCpChunk * kCouplingWeights;
+
+typedef __attribute__((address_space(3))) void* cp_lds_ptr;
+typedef __attribute__((address_space(1))) const void* cp_glb_ptr;
+
+// Requests chunk [rc0, rc0 + 8) of everything this wave needs into `tile` (points past the grid are clamped to
+// the last one; the weights array is padded on the host).  LDS image per plane: [point][mode], so the 8 modes of
+// one point sit in 8 consecutive doubles (conflict-free reads, each shared by 8 lanes).  One DMA instruction
+// moves 256 B = 4 points x 8 modes; lane -> (point, mode, half of the double).
+PDEV void coupling_stage(const CouplingArgs& a, size_t l0, size_t r0, size_t rc0, double* tile, int lane) {
+  const size_t np = a.n_pts, M = a.n_modes;
+  const int pt_in = lane >> 4, mode_in = (lane >> 1) & 7, word = lane & 1;
+  size_t lmode = l0 + mode_in, rmode = r0 + mode_in;
+  lmode = lmode < M ? lmode : M - 1;
+  rmode = rmode < M ? rmode : M - 1;
+  constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
+#pragma unroll
+  for (int pl = 0; pl < 9; ++pl) {
+    const double* row = a.fields + ((pl < 4 ? lmode : rmode) * kPostFields + kPlanes[pl]) * np;
+#pragma unroll
+    for (int h = 0; h < kCpChunk / 4; ++h) {
+      size_t pt = rc0 + h * 4 + pt_in;
+      pt = pt < np ? pt : np - 1;
+      const char* src = reinterpret_cast<const char*>(row + pt) + word * 4;
+      __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + h * 32), 4, 0, 0);
+    }
+  }
+  const char* wsrc = reinterpret_cast<const char*>(a.weights + rc0 * kCouplingWeights) + lane * 4;
+#pragma unroll
+  for (int qd = 0; qd < kCpChunk * kCouplingWeights * 8 / 256; ++qd)
+    __builtin_amdgcn_global_load_lds((cp_glb_ptr)(wsrc + qd * 256), (cp_lds_ptr)(tile + kCpFieldTile + qd * 32), 4, 0, 0);
+}
+
+__global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) {
+  __shared__ __attribute__((aligned(16))) double tiles[2][kCpTile];
   const int lane = threadIdx.x;
+  const int tl = lane >> 3, tr = lane & 7;
   const size_t M = a.n_modes, np = a.n_pts;
-  const size_t lm_raw = (size_t)blockIdx.x * 8 + (lane >> 3), rm_raw = (size_t)blockIdx.y * 8 + (lane & 7);
-  const bool live = lm_raw < M && rm_raw < M;
-  const size_t lm = lm_raw < M ? lm_raw : M - 1, rm = rm_raw < M ? rm_raw : M - 1;
+  const size_t l0 = (size_t)blockIdx.x * 8, r0 = (size_t)blockIdx.y * 8;
+  const bool live = l0 + tl < M && r0 + tr < M;
+  const size_t lm = l0 + tl < M ? l0 + tl : M - 1, rm = r0 + tr < M ? r0 + tr : M - 1;
   const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lm] * a.n_ell + a.ell_index[rm]) * kCouplingConsts;
   const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
   const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
   const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
   const double k6 = ipr + 6.0 * q2;
   const double rfreq = a.freq[rm];
-  const double* __restrict__ lf = a.fields + lm * kPostFields * np;
-  const double* __restrict__ rf = a.fields + rm * kPostFields * np;
-  const double* __restrict__ l_xr = lf + XI_R * np; const double* __restrict__ l_xh = lf + XI_H * np;
-  const double* __restrict__ l_psi = lf + PSI * np; const double* __restrict__ l_p = lf + PRS * np;
-  const double* __restrict__ r_xr = rf + XI_R * np; const double* __restrict__ r_xh = rf + XI_H * np;
-  const double* __restrict__ r_tp = rf + XI_TP * np; const double* __restrict__ r_tn = rf + XI_TN * np;
-  const double* __restrict__ r_rho = rf + RHO * np;
-  const double* __restrict__ w = a.weights;
+  // this lane's values inside a tile: plane pl, point c, mode k at pl*kCpPlane + c*8 + k
+  const int o_lxr = 0 * kCpPlane + tl, o_lxh = 1 * kCpPlane + tl, o_lpsi = 2 * kCpPlane + tl, o_lp = 3 * kCpPlane + tl;
+  const int o_rxr = 4 * kCpPlane + tr, o_rxh = 5 * kCpPlane + tr, o_rtp = 6 * kCpPlane + tr, o_rtn = 7 * kCpPlane + tr,
+            o_rrho = 8 * kCpPlane + tr;
   double d_squared = 0.0, d_linear = 0.0, d_zero = 0.0, r_linear = 0.0, r_zero = 0.0, l_zero = 0.0;
   bool finite = true;
-#pragma unroll 2
-  for (size_t rc = 1; rc < np; ++rc) {  // src/perturbed.rs:148-261
-    const double* __restrict__ u = w + rc * kCouplingWeights;  // wave-uniform
-    const double lxr = l_xr[rc], lxh = l_xh[rc], lpsi = l_psi[rc], lp = l_p[rc];
-    const double rxr = r_xr[rc], rxh = r_xh[rc], rtpv = r_tp[rc], rtnv = r_tn[rc], rrho = r_rho[rc];
-    const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
-    const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
-    const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
-    double val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
-                              (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
-    finite = finite && isfinite(val);
-    d_squared += val;
-    d_linear += u[CW_C1] * val;
-    d_zero += u[CW_C2] * val;
-    val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
-    const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
-    finite = finite && isfinite(val) && isfinite(val_t);
-    const double mrot = u[CW_MROT];
-    r_linear += mrot * val + val_t;
-    r_zero += mrot * (mrot * val + val_t);
-    const double sig = rfreq - mrot;
-    const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
-    l_zero += u[CW_TR2] *
-              ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) + lpsi * rrho * tea -
-               rho * lpsi * rxr * adtea / x + lpsi * q2 * rrho * teb - rho * lpsi * q2 * rxr * adteb / x - lp * rxr * adtea / x -
-               lp * q2 * rxr * adteb / x - lp * q2_hrd * rxh * teb / x + q2_hrd * rho * lpsi * rxh * teb / x);
-    finite = finite && isfinite(l_zero);
+  coupling_stage(a, l0, r0, 1, tiles[0], lane);
+  int buf = 0;
+  for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk `buf` (requested one chunk ago) has landed
+    __syncthreads();
+    if (rc0 + kCpChunk < np) coupling_stage(a, l0, r0, rc0 + kCpChunk, tiles[buf ^ 1], lane);
+    const double* __restrict__ t = tiles[buf];
+    const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
+    for (int c = 0; c < cnt; ++c) {
+      const double* __restrict__ u = t + kCpFieldTile + c * kCouplingWeights;  // wave-uniform
+      const double lxr = t[o_lxr + c * 8], lxh = t[o_lxh + c * 8], lpsi = t[o_lpsi + c * 8], lp = t[o_lp + c * 8];
+      const double rxr = t[o_rxr + c * 8], rxh = t[o_rxh + c * 8], rtpv = t[o_rtp + c * 8], rtnv = t[o_rtn + c * 8],
+                   rrho = t[o_rrho + c * 8];
+      const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+      const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
+      const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
+      double val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
+                                (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+      finite = finite && isfinite(val);
+      d_squared += val;
+      d_linear += u[CW_C1] * val;
+      d_zero += u[CW_C2] * val;
+      val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+      const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
+      finite = finite && isfinite(val) && isfinite(val_t);
+      const double mrot = u[CW_MROT];
+      r_linear += mrot * val + val_t;
+      r_zero += mrot * (mrot * val + val_t);
+      const double sig = rfreq - mrot;
+      const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
+      // the six divisions by r share one refined reciprocal (shared_div.hpp: same bits as six real divisions)
+      double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
+                      lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
+      shared_div6(dv, shared_div_prepare(x));
+      l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
+                             lpsi * rrho * tea - dv[0] + lpsi * q2 * rrho * teb - dv[1] - dv[2] - dv[3] - dv[4] + dv[5]);
+      finite = finite && isfinite(l_zero);
+    }
+    buf ^= 1;
   }
   if (live) {
     const size_t at = lm + rm * M, mm = M * M;

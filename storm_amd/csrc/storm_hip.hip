@@ -836,7 +836,7 @@ int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, co
     DeviceGuard g(p->device);
     const size_t np = p->model.n_pts;
     // per-point weights: the mode-independent sub-expressions of src/perturbed.rs:88-108,157-252
-    std::vector<double> w(np * kCouplingWeights, 0.0);
+    std::vector<double> w((np + 16) * kCouplingWeights, 0.0);  // one chunk of zero padding: the kernel stages 16 points at a time
     const double mf = double(m);
     for (size_t i = 0; i < np; ++i) {
       double* u = w.data() + i * kCouplingWeights;
