@@ -185,8 +185,12 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   constexpr int kGroup = hex_group_stride(LPF);
   constexpr bool kPrefetch = hex_prefetch(SCHEME, LPF);
   constexpr int kTile = kPrefetch ? hex_coef_rows(SCHEME, LPF) * LPF : 2;  // doubles per coefficient tile
-  __shared__ __attribute__((aligned(16))) double lds[kFreqs * kGroup];
-  __shared__ __attribute__((aligned(16))) double coef[2 * kTile];
+  // ONE shared array for the step-matrix hand-off and the two coefficient tiles: with a second __shared__ object
+  // beside the LDS-DMA target hipcc waits vmcnt(0) before the first ds_read after every DMA issue, which drains the
+  // prefetch at once (seen in the .s; cdna_hip_programming.md, "three .s-level traps").
+  constexpr int kHandOff = (kFreqs * kGroup + 1) / 2 * 2;  // doubles, keeps the tiles 16-B aligned
+  __shared__ __attribute__((aligned(16))) double lds[kHandOff + 2 * kTile];
+  double* const coef = lds + kHandOff;
   const int tid = threadIdx.x;
   const int g = tid / LPF;    // frequency within the wave
   const int sub = tid % LPF;  // interval within the round (phase A)
