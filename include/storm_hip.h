@@ -176,6 +176,16 @@ int storm_coupling_matrices(storm_postproc* post, size_t n, const uint64_t* ell,
  * on this handle; measurement aid, no counterpart in the reference. */
 double storm_postproc_last_kernel_ms(const storm_postproc* post);
 
+/* ---- Memory cache (no counterpart in the reference) ----
+ * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
+ * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent
+ * small scans of a rotation sweep (one handle per (ell, m, rotation rate) system).  Defaults: up to 16 GiB of device
+ * memory and 2 GiB of pinned host memory stay cached.  A caller that used storm_det_batch_device with its own stream
+ * must synchronise that stream before destroying the handle. */
+int storm_memory_cache_trim(void);                                            /* give everything cached back to HIP */
+int storm_memory_cache_limit(size_t device_bytes, size_t pinned_host_bytes);  /* what may stay cached from now on */
+void storm_memory_cache_stats(size_t* device_bytes, size_t* pinned_host_bytes); /* currently cached (either may be NULL) */
+
 /* Precision::Relative(p).as_ulp(), src/bracket.rs:30-40. */
 uint64_t storm_precision_relative_to_ulp(double relative_precision);
 

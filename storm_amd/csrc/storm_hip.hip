@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -57,33 +58,135 @@ static void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) fail(STORM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// Growable device buffer.
+// Process-wide cache of device buffers, pinned host buffers and streams.  hipFree / hipHostFree / hipStreamDestroy
+// synchronise the whole device and hipMalloc / hipHostMalloc cost 0.1-1 ms: with one handle per small scan (the
+// rotation sweeps of the reference's batch scripts run thousands of 100-300 frequency scans, each on its own system)
+// they serialised concurrent scans (scripts/many_scans_bench.py).  Blocks are kept by size and handed to the next
+// handle that asks; only what exceeds the cache limit goes back to the runtime.  A block is given back only after
+// the stream that used it has been synchronised (see DevBuf::reserve and the destroy functions).
+class MemoryCache {
+ public:
+  static MemoryCache& get() { static MemoryCache m; return m; }
+  static size_t size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    if (bytes < (size_t(1) << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+    return (bytes + (size_t(1) << 20) - 1) >> 20 << 20;
+  }
+  void* take(bool pinned, int dev, size_t bytes, size_t& granted) {
+    granted = size_class(bytes);
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto& m = blocks_[key(pinned, dev)];
+      auto it = m.lower_bound(granted);
+      if (it != m.end() && it->first <= granted + granted / 4 + (size_t(1) << 20)) {  // close enough in size
+        void* p = it->second;
+        granted = it->first;
+        cached_[pinned] -= granted;
+        m.erase(it);
+        return p;
+      }
+    }
+    void* p = nullptr;
+    hipError_t e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
+    if (e != hipSuccess) {  // make room and try once more
+      trim();
+      e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
+    }
+    hip_check(e, pinned ? "hipHostMalloc" : "hipMalloc");
+    return p;
+  }
+  void give(bool pinned, int dev, void* p, size_t granted) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      if (cached_[pinned] + granted <= limit_[pinned]) {
+        blocks_[key(pinned, dev)].emplace(granted, p);
+        cached_[pinned] += granted;
+        return;
+      }
+    }
+    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+  }
+  hipStream_t take_stream(int dev) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto& v = streams_[dev];
+      if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
+    }
+    hipStream_t st = nullptr;
+    hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    return st;
+  }
+  void give_stream(int dev, hipStream_t st) {  // st must be idle
+    if (!st) return;
+    std::lock_guard<std::mutex> lock(mu_);
+    auto& v = streams_[dev];
+    if (v.size() < 64) { v.push_back(st); return; }
+    (void)hipStreamDestroy(st);
+  }
+  // Returns every cached block to the runtime (each device's blocks with that device current).
+  void trim() {
+    std::map<int, std::multimap<size_t, void*>> blocks;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      blocks.swap(blocks_);
+      cached_[0] = cached_[1] = 0;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (auto& kv : blocks) {
+      const bool pinned = kv.first & 1;
+      if (!pinned) (void)hipSetDevice(kv.first >> 1);
+      for (auto& b : kv.second) { if (pinned) (void)hipHostFree(b.second); else (void)hipFree(b.second); }
+    }
+    (void)hipSetDevice(prev);
+  }
+  void set_limit(bool pinned, size_t bytes) { std::lock_guard<std::mutex> lock(mu_); limit_[pinned] = bytes; }
+  size_t cached(bool pinned) { std::lock_guard<std::mutex> lock(mu_); return cached_[pinned]; }
+
+ private:
+  static int key(bool pinned, int dev) { return dev * 2 + (pinned ? 1 : 0); }
+  std::mutex mu_;
+  std::map<int, std::multimap<size_t, void*>> blocks_;
+  std::map<int, std::vector<hipStream_t>> streams_;
+  size_t cached_[2] = {0, 0};
+  size_t limit_[2] = {size_t(16) << 30, size_t(2) << 30};  // device, pinned host
+};
+
+// Growable device buffer (blocks come from / go back to the MemoryCache).
 template <class T>
 struct DevBuf {
   T* p = nullptr;
-  size_t cap = 0;
-  void reserve(size_t n) {
+  size_t cap = 0;       // elements usable
+  size_t granted = 0;   // bytes of the block
+  int dev = 0;
+  // `st`: the stream whose work may still be using the current block; it is synchronised before the block is recycled
+  void reserve(size_t n, hipStream_t st = nullptr) {
     if (n <= cap) return;
-    if (p) hip_check(hipFree(p), "hipFree");
+    if (p) {
+      hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+      MemoryCache::get().give(false, dev, p, granted);
+    }
     p = nullptr; cap = 0;
-    hip_check(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)), "hipMalloc");
-    cap = n;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    p = static_cast<T*>(MemoryCache::get().take(false, dev, n * sizeof(T), granted));
+    cap = granted / sizeof(T);
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) MemoryCache::get().give(false, dev, p, granted); p = nullptr; cap = 0; }
 };
 
 // Growable pinned host buffer (staging for large device-to-host results).
 struct PinnedBuf {
   double* p = nullptr;
-  size_t cap = 0;
-  void reserve(size_t n) {
+  size_t cap = 0, granted = 0;
+  void reserve(size_t n) {  // callers have synchronised the stream that last wrote it
     if (n <= cap) return;
-    if (p) hip_check(hipHostFree(p), "hipHostFree");
+    if (p) MemoryCache::get().give(true, 0, p, granted);
     p = nullptr; cap = 0;
-    hip_check(hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(double), hipHostMallocDefault), "hipHostMalloc");
-    cap = n;
+    p = static_cast<double*>(MemoryCache::get().take(true, 0, n * sizeof(double), granted));
+    cap = granted / sizeof(double);
   }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) MemoryCache::get().give(true, 0, p, granted); p = nullptr; cap = 0; }
 };
 
 }  // namespace storm
@@ -101,7 +204,7 @@ struct storm_solver {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
   DevBuf<int> d_swaps, d_flags;
-  PinnedBuf h_vec;
+  PinnedBuf h_vec, h_flags;
   int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
   int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad, 4 hex
   size_t steps_bytes_max = size_t(4) << 30;
@@ -112,6 +215,7 @@ struct storm_solver {
   int hex_lanes = 0;                             // lanes per frequency of that kernel: 0 = by wave-slot packing, 16, 32
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
+  hipEvent_t sync_marker = nullptr;
   bool profile = false;
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
@@ -126,6 +230,14 @@ struct storm_postproc {
   int device = 0;
   PostModelDev model{};
   DevBuf<double> tab;
+  // The model planes wait in pinned memory and are uploaded by the first call that needs them, on the stream that
+  // call runs on (for storm_modes_batch: the solver's), so creating a handle costs no device work and no wait behind
+  // other scans' kernels; the handle's own stream is taken only if an entry point needs one.
+  PinnedBuf h_model;
+  size_t tab_elems = 0;
+  bool uploaded = false;
+  hipStream_t upload_stream = nullptr;
+  hipEvent_t ready = nullptr, sync_marker = nullptr;
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_vec, d_terms, d_scale, d_fields, d_nodes;
   DevBuf<long long> d_ids;
@@ -253,10 +365,24 @@ void resolve_timers(storm_solver* s) {
   s->pending.clear();
 }
 
+// Waits for everything submitted to `st` so far.  An event is recorded behind the last command first: with many
+// handles in flight (one stream each, more streams than hardware queues) hipStreamSynchronize alone has to push its
+// own marker through a queue that the hardware scheduler may have unmapped by then, which cost ~10 ms per call in
+// tools/many_scans.cpp; with the event already queued behind the kernel the wait returns when the kernel does
+// (64 scans on 16 threads: 140-175 ms -> 95 ms).
+void sync_stream(hipStream_t st, hipEvent_t& marker) {
+  if (!marker) hip_check(hipEventCreateWithFlags(&marker, hipEventDisableTiming), "hipEventCreate");
+  hip_check(hipEventRecord(marker, st), "hipEventRecord");
+  hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+
 void check_flags(storm_solver* s) {
-  int flags = 0;
-  hip_check(hipMemcpyAsync(&flags, s->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, s->stream), "flags D2H");
-  hip_check(hipStreamSynchronize(s->stream), "sync");
+  // the flag word lands in pinned memory (a copy to pageable memory takes the runtime's staged, host-synchronous path)
+  s->h_flags.reserve(1);
+  int* flags_ptr = reinterpret_cast<int*>(s->h_flags.p);
+  hip_check(hipMemcpyAsync(flags_ptr, s->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, s->stream), "flags D2H");
+  sync_stream(s->stream, s->sync_marker);
+  const int flags = *flags_ptr;
   resolve_timers(s);
   if (flags & 1) {
     hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags reset");
@@ -299,7 +425,7 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     if (chunk == 0) chunk = 1;
     if (chunk > n) chunk = n;
     if (chunk > 65535) chunk = 65535;  // grid.y limit
-    s->d_steps.reserve(chunk * n_int * 16);
+    s->d_steps.reserve(chunk * n_int * 16, st);
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
       ScopedTimer tb(s, st, STORM_KERNEL_BUILD_STEPS);
@@ -316,8 +442,8 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
 
 void det_host(storm_solver* s, const double* freq, size_t n, double* det_out) {
   if (n == 0) return;
-  s->d_freq.reserve(n);
-  s->d_det.reserve(n);
+  s->d_freq.reserve(n, s->stream);
+  s->d_det.reserve(n, s->stream);
   hip_check(hipMemcpyAsync(s->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
   det_device(s, s->d_freq.p, n, s->d_det.p, s->stream);
   hip_check(hipMemcpyAsync(det_out, s->d_det.p, n * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
@@ -417,11 +543,11 @@ size_t eigen_reserve(storm_solver* s, size_t n) {
   if (chunk == 0) chunk = 1;
   if (chunk > n) chunk = n;
   if (chunk > 65535) chunk = 65535;
-  s->d_freq.reserve(chunk); s->d_det.reserve(chunk);
-  s->d_steps.reserve(chunk * n_int * 16 + 16);
-  s->d_upper.reserve(chunk * ustride);
-  s->d_vec.reserve(chunk * len);
-  s->d_swaps.reserve(chunk * 2);
+  s->d_freq.reserve(chunk, s->stream); s->d_det.reserve(chunk, s->stream);
+  s->d_steps.reserve(chunk * n_int * 16 + 16, s->stream);
+  s->d_upper.reserve(chunk * ustride, s->stream);
+  s->d_vec.reserve(chunk * len, s->stream);
+  s->d_swaps.reserve(chunk * 2, s->stream);
   return chunk;
 }
 // Eigenvectors of m host frequencies into s->d_vec (and discriminants into s->d_det), left on the device.
@@ -490,6 +616,24 @@ PostParams post_params(uint64_t ell, int64_t m) {  // src/postprocessing.rs:85-9
   q.ellf = double(ell);
   return q;
 }
+hipStream_t post_stream(storm_postproc* p) {
+  if (!p->stream) p->stream = MemoryCache::get().take_stream(p->device);
+  return p->stream;
+}
+// Makes the model planes available to work submitted on `st` after this call.
+void ensure_model(storm_postproc* p, hipStream_t st) {
+  if (!p->uploaded) {
+    p->tab.reserve(p->tab_elems, st);
+    hip_check(hipMemcpyAsync(p->tab.p, p->h_model.p, p->tab_elems * sizeof(double), hipMemcpyHostToDevice, st), "model H2D");
+    hip_check(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventRecord(p->ready, st), "hipEventRecord");
+    p->model.tab = p->tab.p;
+    p->upload_stream = st;
+    p->uploaded = true;
+  } else if (st != p->upload_stream) {
+    hip_check(hipStreamWaitEvent(st, p->ready, 0), "hipStreamWaitEvent");
+  }
+}
 size_t post_reserve(storm_postproc* p, size_t n, bool fields, size_t node_cap) {
   const size_t np = p->model.n_pts;
   const size_t per_mode = (np * (1 + 4 + (fields ? kPostFields : 0)) + node_cap + 8) * sizeof(double);
@@ -497,11 +641,11 @@ size_t post_reserve(storm_postproc* p, size_t n, bool fields, size_t node_cap) {
   if (chunk == 0) chunk = 1;
   if (chunk > n) chunk = n;
   if (chunk > 65535) chunk = 65535;
-  p->d_terms.reserve(chunk * np);
-  p->d_scale.reserve(chunk);
-  p->d_ids.reserve(chunk * 4);
-  if (fields) p->d_fields.reserve(chunk * kPostFields * np);
-  if (node_cap) p->d_nodes.reserve(chunk * node_cap);
+  p->d_terms.reserve(chunk * np, p->stream);
+  p->d_scale.reserve(chunk, p->stream);
+  p->d_ids.reserve(chunk * 4, p->stream);
+  if (fields) p->d_fields.reserve(chunk * kPostFields * np, p->stream);
+  if (node_cap) p->d_nodes.reserve(chunk * node_cap, p->stream);
   return chunk;
 }
 void post_chunk(storm_postproc* p, const PostParams& par, const double* d_freq, const double* d_vec, size_t k, bool fields,
@@ -522,7 +666,7 @@ void post_download(storm_postproc* p, size_t k, double* fields_out, storm_mode_i
   if (nf) hip_check(hipMemcpyAsync(p->h_stage.p, p->d_fields.p, nf * sizeof(double), hipMemcpyDeviceToHost, st), "fields D2H");
   if (nn) hip_check(hipMemcpyAsync(p->h_stage.p + nf, p->d_nodes.p, nn * sizeof(double), hipMemcpyDeviceToHost, st), "nodes D2H");
   hip_check(hipMemcpyAsync(p->h_ids.data(), p->d_ids.p, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, st), "ids D2H");
-  hip_check(hipStreamSynchronize(st), "postprocess");
+  sync_stream(st, p->sync_marker);
   if (nf) std::memcpy(fields_out, p->h_stage.p, nf * sizeof(double));
   if (nn) std::memcpy(nodes_out, p->h_stage.p + nf, nn * sizeof(double));
   for (size_t i = 0; i < k; ++i)
@@ -569,17 +713,23 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     const double ell = double(d->ell);
     s->ell0 = (ell == 0.0);
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
-    s->tab.reserve(tab.size() ? tab.size() : 1);
-    hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+    s->tab.reserve(tab.size() ? tab.size() : 1, nullptr);
+    s->stream = MemoryCache::get().take_stream(s->device);
     // Uploads are ordered on the solver's own (non-blocking) stream: a plain hipMemcpy from pageable
     // memory is only ordered against the NULL stream, so a kernel launched on s->stream right after
     // create could otherwise read the planes before the DMA has landed.
-    if (!tab.empty())
-      hip_check(hipMemcpyAsync(s->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
+    // (staged through a cached pinned buffer: a copy from pageable memory goes through the runtime's own staging
+    // path, which serialises concurrent creates)
+    if (!tab.empty()) {
+      s->h_vec.reserve(tab.size());
+      std::memcpy(s->h_vec.p, tab.data(), tab.size() * sizeof(double));
+      hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, tab.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
                 "planes H2D");
+    }
     s->d_flags.reserve(1);
     hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags memset");
-    hip_check(hipStreamSynchronize(s->stream), "create sync");
+    // no wait: every later kernel of this handle runs on the same stream, behind the upload; the pinned staging
+    // buffer belongs to the handle and is next written only after a synchronisation of that stream
     s->sys.tab = s->tab.p;
     s->sys.stride = padded_stride(d->n_int);
     s->sys.plane = s->sys.stride * d->p;
@@ -605,11 +755,12 @@ void storm_solver_destroy(storm_solver* s) {
   int prev = 0;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(s->device);
-  if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-  for (auto& t : s->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  if (s->stream) { (void)hipStreamSynchronize(s->stream); MemoryCache::get().give_stream(s->device, s->stream); }
+  for (auto& t : s->pending) { if (t.start) (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
+  if (s->sync_marker) (void)hipEventDestroy(s->sync_marker);
   s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
-  s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release();
+  s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release(); s->h_flags.release();
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -632,6 +783,7 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
       s->arith = int(value);
     } else if (k == "profile") {
       s->profile = value != 0;
+
     } else if (k == "hex_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
       s->hex_min_n = size_t(value);
@@ -763,21 +915,19 @@ int storm_postproc_create(const storm_model_desc* d, storm_postproc** out) {
     const size_t np = d->n_pts;
     if (np < 2) fail(STORM_ERR_INVALID_ARGUMENT, "the model needs at least two points");
     if (d->r_coord[0] != 0.0) fail(STORM_ERR_INVALID_ARGUMENT, "r_coord[0] must be 0 (assert_eq! in Rotating1DPostprocessing::new)");
-    std::vector<double> tab(size_t(kPostPlanes) * np);
+    std::unique_ptr<storm_postproc> p(new storm_postproc());
+    hip_check(hipGetDevice(&p->device), "hipGetDevice (is a HIP device present?)");
+    p->tab_elems = size_t(kPostPlanes) * np;
+    p->h_model.reserve(p->tab_elems);
+    double* tab = p->h_model.p;
     static_assert(PP_R == 0 && PP_ROT == 9 && PP_TRAP == 10, "plane order");
-    for (int f = 0; f < 10; ++f) std::memcpy(tab.data() + size_t(f) * np, src[f], np * sizeof(double));
-    double* trap = tab.data() + size_t(PP_TRAP) * np;  // src/postprocessing.rs:99-111
+    for (int f = 0; f < 10; ++f) std::memcpy(tab + size_t(f) * np, src[f], np * sizeof(double));
+    double* trap = tab + size_t(PP_TRAP) * np;  // src/postprocessing.rs:99-111
     const double* r = d->r_coord;
     trap[0] = 0.5 * (r[1] - r[0]);
     trap[np - 1] = 0.5 * (r[np - 1] - r[np - 2]);
     for (size_t i = 1; i + 1 < np; ++i) trap[i] = 0.5 * (r[i + 1] - r[i - 1]);
-    std::unique_ptr<storm_postproc> p(new storm_postproc());
-    hip_check(hipGetDevice(&p->device), "hipGetDevice (is a HIP device present?)");
-    hip_check(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking), "hipStreamCreate");
-    p->tab.reserve(tab.size());
-    hip_check(hipMemcpyAsync(p->tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, p->stream), "model H2D");
-    hip_check(hipStreamSynchronize(p->stream), "model upload");
-    p->model.tab = p->tab.p;
+    p->model.tab = nullptr;
     p->model.n_pts = np;
     p->h_r.assign(d->r_coord, d->r_coord + np);
     p->h_rho.assign(d->rho, d->rho + np);
@@ -792,7 +942,10 @@ void storm_postproc_destroy(storm_postproc* p) {
   int prev = 0;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(p->device);
-  if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+  if (p->ready) { (void)hipEventSynchronize(p->ready); (void)hipEventDestroy(p->ready); }
+  if (p->sync_marker) (void)hipEventDestroy(p->sync_marker);
+  if (p->stream) { (void)hipStreamSynchronize(p->stream); MemoryCache::get().give_stream(p->device, p->stream); }
+  p->h_model.release();
   p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
   p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
   p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release();
@@ -808,17 +961,19 @@ int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const do
     std::lock_guard<std::mutex> lock(p->mu);
     DeviceGuard g(p->device);
     const PostParams par = post_params(ell, m);
+    hipStream_t st = post_stream(p);
+    ensure_model(p, st);
     const size_t np = p->model.n_pts, len = np * 4;
     const size_t chunk = post_reserve(p, n, fields_out != nullptr, nodes_out ? node_cap : 0);
-    p->d_freq.reserve(chunk);
-    p->d_vec.reserve(chunk * len);
+    p->d_freq.reserve(chunk, p->stream);
+    p->d_vec.reserve(chunk * len, p->stream);
     for (size_t off = 0; off < n; off += chunk) {
       const size_t k = std::min(chunk, n - off);
-      hip_check(hipMemcpyAsync(p->d_freq.p, freq + off, k * sizeof(double), hipMemcpyHostToDevice, p->stream), "freq H2D");
-      hip_check(hipMemcpyAsync(p->d_vec.p, vec + off * len, k * len * sizeof(double), hipMemcpyHostToDevice, p->stream), "vec H2D");
-      post_chunk(p, par, p->d_freq.p, p->d_vec.p, k, fields_out != nullptr, nodes_out ? node_cap : 0, p->stream);
+      hip_check(hipMemcpyAsync(p->d_freq.p, freq + off, k * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+      hip_check(hipMemcpyAsync(p->d_vec.p, vec + off * len, k * len * sizeof(double), hipMemcpyHostToDevice, st), "vec H2D");
+      post_chunk(p, par, p->d_freq.p, p->d_vec.p, k, fields_out != nullptr, nodes_out ? node_cap : 0, st);
       post_download(p, k, fields_out ? fields_out + off * kPostFields * np : nullptr, ids_out + off,
-                    nodes_out ? nodes_out + off * node_cap : nullptr, node_cap, p->stream);
+                    nodes_out ? nodes_out + off * node_cap : nullptr, node_cap, st);
     }
   });
 }
@@ -891,14 +1046,14 @@ int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, co
         }
       }
     const size_t nf = n * kPostFields * np;
-    p->d_fields.reserve(nf);
-    p->d_freq.reserve(n);
-    p->d_weights.reserve(w.size());
-    p->d_consts.reserve(consts.size());
-    p->d_ell_index.reserve(n);
-    p->d_out.reserve(size_t(kCouplingMatrices) * n * n);
-    p->d_cflags.reserve(1);
-    hipStream_t st = p->stream;
+    p->d_fields.reserve(nf, p->stream);
+    p->d_freq.reserve(n, p->stream);
+    p->d_weights.reserve(w.size(), p->stream);
+    p->d_consts.reserve(consts.size(), p->stream);
+    p->d_ell_index.reserve(n, p->stream);
+    p->d_out.reserve(size_t(kCouplingMatrices) * n * n, p->stream);
+    p->d_cflags.reserve(1, p->stream);
+    hipStream_t st = post_stream(p);
     hip_check(hipMemcpyAsync(p->d_fields.p, fields, nf * sizeof(double), hipMemcpyHostToDevice, st), "fields H2D");
     hip_check(hipMemcpyAsync(p->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
     hip_check(hipMemcpyAsync(p->d_weights.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st), "weights H2D");
@@ -918,13 +1073,27 @@ int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, co
     int flags = 0;
     hip_check(hipMemcpyAsync(out, p->d_out.p, size_t(kCouplingMatrices) * n * n * sizeof(double), hipMemcpyDeviceToHost, st), "out D2H");
     hip_check(hipMemcpyAsync(&flags, p->d_cflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
-    hip_check(hipStreamSynchronize(st), "coupling");
+    sync_stream(st, p->sync_marker);
     float kernel_ms = 0.f;
     (void)hipEventElapsedTime(&kernel_ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     p->last_coupling_ms = double(kernel_ms);
     if (flags & 1) fail(STORM_ERR_NON_FINITE, "Not finite number in a coupling integral (the reference asserts, src/perturbed.rs:165-260)");
   });
+}
+
+int storm_memory_cache_trim(void) {
+  return guarded([&] { MemoryCache::get().trim(); });
+}
+int storm_memory_cache_limit(size_t device_bytes, size_t pinned_host_bytes) {
+  return guarded([&] {
+    MemoryCache::get().set_limit(false, device_bytes);
+    MemoryCache::get().set_limit(true, pinned_host_bytes);
+  });
+}
+void storm_memory_cache_stats(size_t* device_bytes, size_t* pinned_host_bytes) {
+  if (device_bytes) *device_bytes = MemoryCache::get().cached(false);
+  if (pinned_host_bytes) *pinned_host_bytes = MemoryCache::get().cached(true);
 }
 
 double storm_postproc_last_kernel_ms(const storm_postproc* p) { return p ? p->last_coupling_ms : 0.0; }
@@ -941,6 +1110,7 @@ int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, si
     std::lock_guard<std::mutex> lock_p(p->mu);
     DeviceGuard g(s->device);
     const PostParams par = post_params(s->ell, s->m);
+    ensure_model(p, s->stream);
     const size_t np = p->model.n_pts, len = np * 4;
     size_t chunk = std::min(eigen_reserve(s, n), post_reserve(p, n, fields_out != nullptr, nodes_out ? node_cap : 0));
     for (size_t off = 0; off < n; off += chunk) {

@@ -60,7 +60,8 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
            "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
            "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postprocess_batch",
-           "storm_modes_batch", "storm_coupling_matrices", "storm_postproc_last_kernel_ms"]
+           "storm_modes_batch", "storm_coupling_matrices", "storm_postproc_last_kernel_ms",
+           "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats"]
 
 _lib = None
 
@@ -101,6 +102,9 @@ def load_library():
                                     C.c_size_t]
     L.storm_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), _dp, _dp, C.c_int64,
                                           C.POINTER(MetricDesc), _dp]
+    L.storm_memory_cache_limit.argtypes = [C.c_size_t, C.c_size_t]
+    L.storm_memory_cache_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.storm_memory_cache_stats.restype = None
     L.storm_postproc_last_kernel_ms.restype = C.c_double
     L.storm_postproc_last_kernel_ms.argtypes = [C.c_void_p]
     _lib = L
@@ -129,6 +133,21 @@ def _f64(a):
 
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+def memory_cache_stats():
+    """(device bytes, pinned host bytes) currently held by the library's buffer cache."""
+    d, h = C.c_size_t(0), C.c_size_t(0)
+    load_library().storm_memory_cache_stats(C.byref(d), C.byref(h))
+    return int(d.value), int(h.value)
+
+
+def memory_cache_trim():
+    _check(load_library().storm_memory_cache_trim())
+
+
+def memory_cache_limit(device_bytes, pinned_host_bytes):
+    _check(load_library().storm_memory_cache_limit(device_bytes, pinned_host_bytes))
 
 
 def relative_to_ulp(rel):
