@@ -13,6 +13,13 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+def same_bits(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype != np.float64:
+        return np.array_equal(a, b)
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
 def hip_from_oracle(o):
     import storm_amd
     return storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
@@ -190,3 +197,52 @@ def test_full_size_config5_g_modes(oracle, golden_dir):
             _, rvec = o.eigenvector(roots[sel], threads=16)
             _, gvec = h.eigenvector(roots)
             assert np.array_equal(bits(rvec), bits(gvec[sel]))
+
+
+def test_handle_per_scan_from_many_threads_and_memory_cache(oracle, golden_dir):
+    # the rotation-sweep pattern: every thread creates its own solver + post-processing handle,
+    # scans, identifies the modes and destroys both; buffers and streams are recycled through the library's cache.
+    # Results must equal the sequential ones bit for bit, and trimming the cache must not disturb later calls.
+    import storm_amd
+    from storm_amd import ffi
+    jobs = [((ell, m), 0.01 + 0.003 * k) for k, (ell, m) in enumerate([(0, 0), (1, 1), (2, -1), (2, 0), (3, 0), (1, -1)] * 3)]
+    freqs = oracle.linspace(2.0, 14.0, 120)
+    ulp = oracle.relative_to_ulp(1e-8)
+
+    def run(job):
+        (ell, m), rot = job
+        model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_zams.npz"))
+        model.set_rotation_constant(rot)
+        o = oracle.Solver(model, ell, m, "colloc4", model.field("r_coord"))
+        h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+        post = storm_amd.HipPostproc({k: model.field(k) for k in storm_amd.MODEL_FIELDS})
+        res, dets, _ = h.scan_and_optimize(freqs, ulp)
+        got = h.modes(post, np.array([b["root"] for b in res]), want_vec=True)
+        h.close()
+        post.close()
+        return dets, got["vec"], got["fields"], got["ids"]
+
+    sequential = [run(j) for j in jobs]
+    assert ffi.memory_cache_stats()[0] > 0            # destroyed handles left their blocks in the cache
+    out = [None] * len(jobs)
+
+    def worker(k):
+        out[k] = run(jobs[k])
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(sequential, out):
+        for x, y in zip(a, b):
+            assert same_bits(x, y)
+    ffi.memory_cache_trim()
+    assert ffi.memory_cache_stats() == (0, 0)
+    again = run(jobs[0])
+    for x, y in zip(sequential[0], again):
+        assert same_bits(x, y)
+    ffi.memory_cache_limit(0, 0)                       # nothing may stay cached: every release goes back to HIP
+    run(jobs[1])
+    assert ffi.memory_cache_stats() == (0, 0)
+    ffi.memory_cache_limit(16 << 30, 2 << 30)
