@@ -200,6 +200,16 @@ int storm_host_modes(void* p, void* solver, const double* roots, size_t n, int w
   });
 }
 
+// perturb_structure through the mirror: out6 = alpha, dalpha, ddalpha, beta, dbeta, ddbeta (each [n_pts]).
+int storm_host_perturb_structure(void* m, double rot, double* const* out6, double* mass_delta) {
+  return guarded([&] {
+    const PerturbedMetric pm = perturb_structure(static_cast<HostModel*>(m)->discrete, rot);
+    const std::vector<double>* src[6] = {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta};
+    for (int k = 0; k < 6; ++k) std::memcpy(out6[k], src[k]->data(), src[k]->size() * sizeof(double));
+    if (mass_delta) *mass_delta = pm.mass_delta;
+  });
+}
+
 // perturb_deformed's integrals through the mirror: fields [n][13][n_pts], metric6 = alpha, dalpha, ddalpha, beta, dbeta,
 // ddbeta; out [6][n*n] column-major per matrix.
 int storm_host_coupling_matrices(void* p, size_t n, const uint64_t* ells, const double* freqs, const double* fields,

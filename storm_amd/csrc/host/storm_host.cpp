@@ -421,6 +421,105 @@ std::vector<Rotating1DPostprocessing> PostProcessor::modes(const ErasedSolver& s
   return unpack(n, fields, ids, nodes, np);
 }
 
+// ---- perturb_structure (perturbed.rs:324-460) ----
+namespace {
+// nalgebra's closed-form inverses of 2x2 and 3x3 matrices (row-major m[r][c] here); false if the determinant is zero.
+bool invert2(const double (&m)[2][2], double (&o)[2][2]) {
+  const double det = m[0][0] * m[1][1] - m[1][0] * m[0][1];
+  if (det == 0.) return false;
+  o[0][0] = m[1][1] / det; o[0][1] = -m[0][1] / det; o[1][0] = -m[1][0] / det; o[1][1] = m[0][0] / det;
+  return true;
+}
+bool invert3(const double (&m)[3][3], double (&o)[3][3]) {
+  const double c0 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  const double c1 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+  const double c2 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+  const double det = m[0][0] * c0 - m[0][1] * c1 + m[0][2] * c2;
+  if (det == 0.) return false;
+  o[0][0] = c0 / det;
+  o[0][1] = (m[0][2] * m[2][1] - m[2][2] * m[0][1]) / det;
+  o[0][2] = (m[0][1] * m[1][2] - m[1][1] * m[0][2]) / det;
+  o[1][0] = -c1 / det;
+  o[1][1] = (m[0][0] * m[2][2] - m[2][0] * m[0][2]) / det;
+  o[1][2] = (m[0][2] * m[1][0] - m[1][2] * m[0][0]) / det;
+  o[2][0] = c2 / det;
+  o[2][1] = (m[0][1] * m[2][0] - m[2][1] * m[0][0]) / det;
+  o[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) / det;
+  return true;
+}
+// nalgebra product a*b for N x N: every result column is an axpy over the columns of a, k ascending
+template <int N>
+void product(const double (&a)[N][N], const double (&b)[N][N], double (&c)[N][N]) {
+  for (int j = 0; j < N; ++j) {
+    for (int r = 0; r < N; ++r) c[r][j] = a[r][0] * b[0][j];
+    for (int k = 1; k < N; ++k)
+      for (int r = 0; r < N; ++r) c[r][j] = a[r][k] * b[k][j] + c[r][j];
+  }
+}
+}  // namespace
+
+PerturbedMetric perturb_structure(const DiscreteModel& model, double rot) {
+  const DimensionlessProperties& d = model.dimensionless;
+  const size_t np = d.r_coord.size();
+  if (np < 2) throw std::runtime_error("perturb_structure: the model needs at least two points");
+  const std::vector<double>& x = d.r_coord;
+  auto dlnrho = [&](size_t i) { return -d.a_star[i] - d.v[i] / d.gamma1[i]; };
+  auto kappa = [&](size_t i) { return 4. * kPi / d.m_coord[i] * d.rho[i] * x[i] * dlnrho(i); };
+  // the two linear recurrences (P0 and P2 parts of the potential perturbation), implicit midpoint steps
+  std::vector<double> p0a(np, 0.), p0b(np, 0.), p2a(np, 0.), p2b(np, 0.);
+  p2a[1] = 1.; p2b[1] = 2.;
+  for (size_t i = 1; i < np; ++i) {
+    const double delta = x[i] - x[i - 1], mid = 0.5 * (x[i] + x[i - 1]);
+    const double k = kappa(i), k_prev = i == 1 ? 0. : kappa(i - 1);
+    const double w = 0.5 * delta / mid;
+    const double coupling = 0.5 * (mid * mid) * (k + k_prev);
+    {
+      const double a[3][3] = {{w * -1., w * 1., w * 0.}, {w * coupling, w * -2., w * mid}, {w * 0., w * 0., w * 0.}};
+      double lhs[3][3], rhs[3][3], inv[3][3], step[3][3];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { const double e = r == c ? 1. : 0.; lhs[r][c] = e - a[r][c]; rhs[r][c] = e + a[r][c]; }
+      if (!invert3(lhs, inv)) throw std::runtime_error("perturb_structure: singular step (the reference unwraps try_inverse)");
+      product<3>(inv, rhs, step);
+      const double ya = p0a[i - 1], yb = p0b[i - 1];
+      p0a[i] = (step[0][1] * yb + step[0][0] * ya) + step[0][2];
+      p0b[i] = (step[1][1] * yb + step[1][0] * ya) + step[1][2];
+    }
+    if (i != 1) {
+      const double a[2][2] = {{w * -1., w * 1.}, {w * (6. + coupling), w * -2.}};
+      double lhs[2][2], rhs[2][2], inv[2][2], step[2][2];
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 2; ++c) { const double e = r == c ? 1. : 0.; lhs[r][c] = e - a[r][c]; rhs[r][c] = e + a[r][c]; }
+      if (!invert2(lhs, inv)) throw std::runtime_error("perturb_structure: singular step (the reference unwraps try_inverse)");
+      product<2>(inv, rhs, step);
+      const double ya = p2a[i - 1], yb = p2b[i - 1];
+      p2a[i] = step[0][1] * yb + step[0][0] * ya;
+      p2b[i] = step[1][1] * yb + step[1][0] * ya;
+    }
+  }
+  const double a2 = -5. / 6. / (3. * p2a[np - 1] + p2b[np - 1]);
+  PerturbedMetric pm;
+  pm.rot = rot;
+  for (std::vector<double>* v : {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta}) v->assign(np, 0.);
+  const double rot2 = rot * rot;
+  double mass = 0.;
+  for (size_t i = 1; i < np; ++i) {
+    const double dl = dlnrho(i), k = kappa(i), u = d.u[i], xi = x[i];
+    const double trap = i + 1 < np ? 0.5 * (x[i + 1] - x[i - 1]) : 0.5 * (x[np - 1] - x[np - 2]);
+    auto metric = [&](double psi, double dpsi, double ddpsi, double& f, double& df, double& ddf) {
+      const double g = xi * dpsi / psi;
+      f = 2. * xi / d.m_coord[i] * psi * rot2;
+      df = f * (1. - u + g);
+      ddf = df * (1. - u + g) + f * (-3. * u - u * dl + u * u + g - g * g + (xi * xi) * ddpsi / psi);
+    };
+    metric(p0a[i] * xi, p0b[i], ((xi * xi) * k * p0a[i] - 2. * p0b[i]) / xi + 1., pm.alpha[i], pm.dalpha[i], pm.ddalpha[i]);
+    metric(p2a[i] * xi * a2, p2b[i] * a2, ((6. + (xi * xi) * k) * p2a[i] - 2. * p2b[i]) / xi * a2, pm.beta[i], pm.dbeta[i],
+           pm.ddbeta[i]);
+    mass += trap * d.rho[i] * (xi * xi) * (3. * pm.alpha[i] + pm.dalpha[i]);
+  }
+  pm.mass_delta = mass * (4. * kPi);
+  return pm;
+}
+
 CouplingMatrices PostProcessor::coupling_matrices(const std::vector<ModeToPerturb>& modes, int64_t m,
                                                   const PerturbedMetric& metric) const {
   const size_t n = modes.size(), np = x_.size();

@@ -169,6 +169,10 @@ struct PerturbedMetric {  // model.rs:104-123
   std::vector<double> alpha, dalpha, ddalpha, beta, dbeta, ddbeta;
   double rot = 0., mass_delta = 0.;
 };
+// perturb_structure (perturbed.rs:324-460): the deformation of the equilibrium structure by uniform rotation `rot`
+// (dynamical units).  A serial recurrence over the grid; stays on the host like in the reference (`deform`, main.rs:840-876).
+PerturbedMetric perturb_structure(const DiscreteModel& model, double rot);
+
 struct ModeToPerturb {  // perturbed.rs:26-33
   uint64_t ell;
   double freq;

@@ -69,6 +69,7 @@ def load_host_library():
     _i64p, _u64p = C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     L.storm_host_post_process.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, _dp, C.c_size_t, _dp, _i64p, _u64p,
                                           _dp, C.c_size_t]
+    L.storm_host_perturb_structure.argtypes = [C.c_void_p, C.c_double, C.POINTER(_dp), _dp]
     L.storm_host_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, _u64p, _dp, _dp, C.c_int64, C.POINTER(_dp), _dp]
     L.storm_host_modes.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _i64p, _u64p, _dp, C.c_size_t]
     L.storm_host_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
@@ -164,6 +165,18 @@ class Model:
         n = L.storm_host_model_grid(self._h, scale, None, 0)
         out = np.empty(n)
         L.storm_host_model_grid(self._h, scale, _p(out), n)
+        return out
+
+    def perturb_structure(self, rot):
+        """perturb_structure (reference src/perturbed.rs:324-460; the `deform` command): dict of the six metric arrays
+        + mass_delta.  Host-side, like in the reference."""
+        arrs = [np.zeros(len(self)) for _ in ffi.METRIC_FIELDS]
+        ptrs = (_dp * 6)(*[_p(a) for a in arrs])
+        md = np.zeros(1)
+        if load_host_library().storm_host_perturb_structure(self._h, rot, ptrs, _p(md)) != 0:
+            raise _err()
+        out = dict(zip(ffi.METRIC_FIELDS, arrs))
+        out["mass_delta"] = float(md[0])
         return out
 
     def eval(self, grid):

@@ -115,3 +115,21 @@ def test_host_polytrope_matches_oracle(oracle):
     assert np.array_equal(host.rev_linspace(0.5, 1.0, 1000), oracle.rev_linspace(0.5, 1.0, 1000))
     p0 = host.Model.Polytrope0(5.0 / 3.0)
     assert np.array_equal(p0.grid(100), oracle.Model.poly0(5.0 / 3.0).grid(100))
+
+
+@pytest.mark.parametrize("name", ["zams", "tams"])
+def test_host_perturb_structure_matches_oracle(oracle, oracle_models, golden_dir, name):
+    # `deform` (src/main.rs:840-876 -> perturb_structure, src/perturbed.rs:324-460) stays on the host; the C++ mirror
+    # and the oracle restate it independently and must agree bit for bit (parity unpinned: no reference test)
+    from storm_amd import host
+    hm = host.Model.from_gsm_npz(os.path.join(golden_dir, f"gsm_{name}.npz"))
+    om = oracle_models(name)
+    for rot in (0.01, 0.1):
+        a, b = hm.perturb_structure(rot), om.perturb_structure(rot)
+        for k in ("alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta"):
+            assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k
+            assert np.all(np.isfinite(a[k])) and a[k][0] == 0.0
+        assert a["mass_delta"] == b["mass_delta"]
+        assert np.all(a["alpha"][1:] > 0) and np.all(a["beta"][1:] < 0)     # P0 expands, P2 flattens the poles
+    a1, a2 = hm.perturb_structure(0.01), hm.perturb_structure(0.02)
+    np.testing.assert_allclose(a2["alpha"], 4.0 * a1["alpha"], rtol=1e-13)   # quadratic in the rotation rate

@@ -141,3 +141,54 @@ def test_non_finite_and_argument_errors(oracle, oracle_models):
         post.coupling_matrices([0], [3.0], np.ones((1, 13, 5)), 0, zero)
     empty = post.coupling_matrices([], [], np.ones((0, 13, grid.size)), 0, zero)
     assert empty["d_squared"].shape == (0, 0)
+
+
+def test_config5_deformed_star_pipeline(oracle, golden_dir):
+    # BASELINE config 5 end to end: tams with set-rotation-constant 0.1 -> deform (perturb_structure, host mirror)
+    # -> scans ell = 0, 2, 4 (GPU) -> post-process (GPU) -> perturb-deformed integrals (GPU).  Checked against the
+    # oracle chain bit for bit, and physically: the generalised eigenproblem the reference assembles from the six
+    # matrices (src/perturbed.rs:265-283; solved here with scipy instead of the reference's QZ) returns every
+    # input frequency shifted by O(rot^2).
+    import scipy.linalg
+    from storm_amd import host
+    rot = 0.1
+    hm = host.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_tams.npz"))
+    hm.set_rotation_constant(rot)
+    grid = hm.field("r_coord")
+    metric = hm.perturb_structure(rot)
+    pp = host.PostProcessor(hm.eval(grid))
+    ells, freqs, fields = [], [], []
+    for ell in (0, 2, 4):
+        s = host.ErasedSolver(hm, ell, 0, "colloc4", grid)
+        res, _ = s.scan_and_optimize(host.linspace(1.0, 12.0, 1500), host.Precision.Relative(1e-10))
+        roots = np.array([r["root"] for r in res])
+        got = pp.modes(s, roots, want_fields=True)
+        ells += [ell] * roots.size
+        freqs += list(roots)
+        fields.append(got["fields"])
+    ells, freqs, fields = np.array(ells, dtype=np.uint64), np.array(freqs), np.concatenate(fields)
+    n = freqs.size
+    assert n >= 30
+    mats = pp.coupling_matrices(ells, freqs, fields, 0, metric)
+    # oracle chain on the same inputs
+    om = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_tams.npz"))
+    om.set_rotation_constant(rot)
+    ometric = om.perturb_structure(rot)
+    for k in ("alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta"):
+        assert same_bits(metric[k], ometric[k]), k
+    ref, _ = om.coupling_matrices(ells, freqs, fields, 0, ometric, threads=16)
+    for k in ref:
+        assert same_bits(ref[k], mats[k]), k
+    # A v = omega B v with A = [[0, 1], [-d_zero + r_zero + l_zero, d_linear - r_linear]], B = [[1, 0], [0, d_squared]]
+    A = np.zeros((2 * n, 2 * n))
+    B = np.zeros((2 * n, 2 * n))
+    A[n:, :n] = -mats["d_zero"] + mats["r_zero"] + mats["l_zero"]
+    A[:n, n:] = np.eye(n)
+    A[n:, n:] = mats["d_linear"] - mats["r_linear"]
+    B[:n, :n] = np.eye(n)
+    B[n:, n:] = mats["d_squared"]
+    w = scipy.linalg.eigvals(A, B)
+    w = np.sort(w[(w.real > 0) & (np.abs(w.imag) < 1e-6)].real)
+    assert w.size == n
+    shift = np.abs(w - np.sort(freqs)) / np.sort(freqs)
+    assert shift.max() < 0.05 and np.median(shift) < 5e-3      # O(rot^2) = 1e-2 at most a few per cent
