@@ -8,7 +8,7 @@
 //                       so the result is bit-identical to the lane-per-frequency kernel.
 //   eigen_forward_kernel  block-bidiagonal elimination with row pivoting that records the packed
 //                       upper factor (reference determinant_inner/UpperResult, src/solver.rs:
-//                       86-161,271-433).  One lane per mode.
+//                       86-161,271-433).  One wave per mode.
 //   eigen_backsub_kernel  back-substitution to the eigenvector (reference src/solver.rs:100-131).
 #include "common_kernels.hpp"
 #include "device_system.hpp"
@@ -95,11 +95,21 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
 
 // ---------------------------------------------------------------------------------------
 // Eigenvector: forward elimination, one wave per mode.
-// Lane j < 8 owns system column j of the 6x8 band (6 values).  For pivot K the owner's column is
-// read into scalar registers with v_readlane, so the pivot search, the row choice and the
-// multipliers are wave-uniform: the row exchange is a uniform branch (no per-lane selects) and
-// nothing but the readlane sits between two pivots.  Arithmetic per entry is exactly the
-// reference's (row_pivot!/column_pivot!/sweep!, src/solver.rs:163-269):
+// Lane j < 8 owns system column j of the 6x8 band (6 values in registers).  A lone wave issues one instruction
+// (vector OR scalar) per ~4 cycles, so the kernel is shaped by instruction count, not by lanes:
+//   * pivot search: every lane searches its own column with 4 instructions per row; the owner's answer (lane K)
+//     is made wave-uniform with ONE v_readlane (instead of reading the whole column into scalar registers first);
+//   * row exchange: the two rows are addressed by the uniform row index (indexed register access; no branches, no
+//     scalar bookkeeping of a second copy of the pivot column);
+//   * the packed factors go to LDS through per-lane offsets fixed at kernel start (lanes without a factor write to a
+//     dump slot), so no execution-mask juggling sits between two pivots;
+//   * the pivot and the multipliers' column are read with v_readlane AFTER the exchange and used straight from
+//     scalar registers;
+//   * the carry of rows 4,5 into the next interval is a DPP row shift (not a ds_bpermute round trip);
+//   * step matrices arrive 8 intervals (1 KB) per LDS-DMA instruction, one block ahead; the 22 packed factors per
+//     interval are parked in LDS and flushed 8 intervals at a time with coalesced stores, so no wait on the
+//     vector-memory counter sits inside an interval.
+// Arithmetic per entry is exactly the reference's (row_pivot!/column_pivot!/sweep!, src/solver.rs:163-269):
 //   m = B[r][K] * (1/pivot);  B[r][j] -= prow[j] * m.
 // ---------------------------------------------------------------------------------------
 SDEV double lane_value(double x, int lane) {  // wave-uniform copy of lane `lane`'s value
@@ -108,41 +118,41 @@ SDEV double lane_value(double x, int lane) {  // wave-uniform copy of lane `lane
   return __hiloint2double(hi, lo);
 }
 
+SDEV double row_shift_left4(double x) {  // lane i <- lane i + 4 (inside each row of 16 lanes; 0 past the row)
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0xf, true);  // row_shl:4
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 // ROWS x COLS elimination step K on column-distributed data.  `b` = this lane's column.
-// `up_base` points at the packed upper row of this pivot; lane j > K stores prow*pinv at [j-K-1].
-template <int ROWS, int COLS, int K>
-SDEV void wave_pivot(double (&b)[6], int j, double& det, double* __restrict__ up_base, bool search_rows) {
-  double ck[6];
-#pragma unroll
-  for (int r = K; r < ROWS; ++r) ck[r] = lane_value(b[r], K);
-  int max_idx = K;
-  if (search_rows) {
-    double max_val = __builtin_fabs(ck[K]);
+// `up_slot` is where THIS lane puts prow*pinv: [j-K-1] of the packed upper row of this pivot for K < j < COLS, a dump
+// slot for every other lane (so the store needs no execution mask).
+template <int ROWS, int COLS, int K, bool SEARCH>
+SDEV void wave_pivot(double (&b)[6], double& det, double* __restrict__ up_slot) {
+  double prow = b[K];
+  if constexpr (SEARCH) {
+    int idx = K;
+    double best = __builtin_fabs(b[K]);
 #pragma unroll
     for (int r = K + 1; r < ROWS; ++r) {
-      const double v = __builtin_fabs(ck[r]);
-      if (v > max_val) { max_idx = r; max_val = v; }
+      const double v = __builtin_fabs(b[r]);
+      const bool gt = v > best;  // strict: the first maximum wins, NaN never does
+      idx = gt ? r : idx;
+      best = gt ? v : best;
     }
-    max_idx = __builtin_amdgcn_readfirstlane(max_idx);
+    const int max_idx = __builtin_amdgcn_readlane(idx, K);  // the owner of column K decides for the wave
+    prow = b[max_idx];   // wave-uniform register index (s_set_gpr_idx): cheaper than selects on every row
+    b[max_idx] = b[K];
+    det = det * (max_idx != K ? -1.0 : 1.0);
   }
-  double prow = b[K];
-  double pivot = ck[K];
-#pragma unroll
-  for (int r = K + 1; r < ROWS; ++r) {
-    if (max_idx == r) {  // wave-uniform
-      prow = b[r];
-      pivot = ck[r];
-      b[r] = b[K];
-      ck[r] = ck[K];
-    }
-  }
-  if (max_idx != K) det = det * -1.0;
+  const double pivot = lane_value(prow, K);
   det = det * pivot;
   const double pinv = 1.0 / pivot;
-  if (j > K && j < COLS) up_base[j - K - 1] = prow * pinv;
+  *up_slot = prow * pinv;
 #pragma unroll
   for (int r = K + 1; r < ROWS; ++r) {
-    const double m = ck[r] * pinv;
+    const double m = lane_value(b[r], K) * pinv;
     b[r] = b[r] - prow * m;
   }
 }
@@ -170,21 +180,36 @@ SDEV int wave_column_swap(double (&b)[6], int j, double& det) {
   return max_idx;
 }
 
-constexpr int kEigBlock = 8;  // intervals per prefetched register block
+constexpr int kEigBlock = 8;                    // intervals per staged block
+constexpr int kEigStepTile = kEigBlock * 16;    // doubles: 8 step matrices, row-major
+constexpr int kEigUpTile = kEigBlock * 22;      // doubles: 8 x 22 packed factors
+
+typedef __attribute__((address_space(3))) void* eig_lds_ptr;
+typedef __attribute__((address_space(1))) const void* eig_glb_ptr;
 
 template <bool ELL0>
 __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                            const double* __restrict__ steps,
                                                            double* __restrict__ upper, int* __restrict__ swaps,
                                                            double* __restrict__ det_out) {
-  const int j = threadIdx.x;   // lanes 0..7 carry the band; the others idle along (their values are never used)
+  // one shared object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every LDS read)
+  __shared__ __attribute__((aligned(16))) double lds[2 * kEigStepTile + 2 * kEigUpTile + 64];
+  double* const up_tiles = lds + 2 * kEigStepTile;
+  double* const dump = lds + 2 * kEigStepTile + 2 * kEigUpTile;  // one slot per lane for factors nobody needs
+  const int lane = threadIdx.x;
+  const int j = lane;          // lanes 0..7 carry the band; the others idle along (their values are never used)
   const size_t m = blockIdx.x;  // one wave per mode
   const double f = freq[m];
   const size_t n_int = s.n_int;
   const size_t ustride = n_int * 22 + 6;
   double* __restrict__ up = upper + m * ustride;
-  // lane j < 4 reads column j of the row-major step matrix: entries j, 4+j, 8+j, 12+j
-  const double* __restrict__ st = steps + m * n_int * 16 + (j & 3);
+  const char* __restrict__ st_bytes = reinterpret_cast<const char*>(steps + m * n_int * 16);
+  const size_t st_last = n_int * 128 - 16;  // last 16-B piece of this mode's step matrices
+  auto stage_steps = [&](size_t i0, double* tile) {  // 8 intervals = 1 KB = one DMA instruction
+    size_t off = i0 * 128 + (size_t)lane * 16;
+    off = off < st_last ? off : st_last;
+    __builtin_amdgcn_global_load_lds((eig_glb_ptr)(st_bytes + off), (eig_lds_ptr)tile, 16, 0, 0);
+  };
   double b[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) b[r] = 0.0;
@@ -194,60 +219,89 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
     b[0] = (j == 0) ? i00 : ((j == 1 || j == 2) ? -s.ell : 0.0);
     b[1] = (j == 2) ? s.ell : ((j == 3) ? -1.0 : 0.0);
   }
-  double det = 1.0;
-  int sw0 = 0, sw1 = 1;
-  double cur[kEigBlock][4], nxt[kEigBlock][4];
-  auto load_block = [&](double (&dst)[kEigBlock][4], size_t i0) {
+  auto flush_factors = [&](size_t i0, const double* tile) {  // block [i0, i0+8): coalesced, 8 B per lane and instruction
+    const size_t cnt = (n_int - i0 < (size_t)kEigBlock ? n_int - i0 : (size_t)kEigBlock) * 22;
 #pragma unroll
-    for (int u = 0; u < kEigBlock; ++u) {
-      const size_t i = (i0 + u < n_int) ? i0 + u : n_int - 1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[u][r] = st[i * 16 + r * 4];
+    for (int qd = 0; qd < (kEigUpTile + 63) / 64; ++qd) {
+      const size_t e = (size_t)qd * 64 + lane;
+      if (e < cnt) up[i0 * 22 + e] = tile[e];
     }
   };
-  if (n_int > 0) load_block(nxt, 0);
+  // where this lane's factor of pivot K goes, relative to the interval's 22 packed values (or to the dump slots)
+  int slot[4];
+  {
+    constexpr int kRowStart[4] = {0, 7, 13, 18};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      slot[k] = (j > k && j < 8) ? kRowStart[k] + j - k - 1 : (int)(dump - up_tiles) + lane;
+  }
+  double det = 1.0;
+  int sw0 = 0, sw1 = 1;
+  if (n_int > 0) stage_steps(0, lds);
+  int buf = 0;
   for (size_t i0 = 0; i0 < n_int; i0 += kEigBlock) {
+    // Everything the vector-memory counter still holds was issued a whole block ago (this block's step matrices,
+    // the flush of the block before the previous one), so this wait does not stall.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i0 + kEigBlock < n_int) stage_steps(i0 + kEigBlock, lds + (buf ^ 1) * kEigStepTile);
+    if (i0 > 0) flush_factors(i0 - kEigBlock, up_tiles + (buf ^ 1) * kEigUpTile);  // the previous block's factors
+    double* const up_tile = up_tiles + buf * kEigUpTile;
+    // lane j < 4 reads column j of each step matrix; the values of interval u+1 are fetched while u is eliminated
+    const double* __restrict__ tile = lds + buf * kEigStepTile + (j & 3);
+    double nl[4];
 #pragma unroll
-    for (int u = 0; u < kEigBlock; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cur[u][r] = nxt[u][r];
-    if (i0 + kEigBlock < n_int) load_block(nxt, i0 + kEigBlock);
+    for (int r = 0; r < 4; ++r) nl[r] = tile[r * 4];
 #pragma unroll
     for (int u = 0; u < kEigBlock; ++u) {
       const size_t i = i0 + u;
+      double cl[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cl[r] = nl[r];
+      if (u + 1 < kEigBlock) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nl[r] = tile[(u + 1) * 16 + r * 4];
+      }
       if (i < n_int) {
         // rows 2..5 <- [L | -I]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r + 2] = (j < 4) ? cur[u][r] : ((j - 4 == r) ? -1.0 : 0.0);
-        double* __restrict__ upi = up + i * 22;
-        if (i == 0) {
+        for (int r = 0; r < 4; ++r) b[r + 2] = (j < 4) ? cl[r] : ((j - 4 == r) ? -1.0 : 0.0);
+        double* __restrict__ upi = up_tile + u * 22;
+        // dump slots are addressed relative to up_tiles: undo the per-buffer, per-interval offset for them
+        auto slot_ptr = [&](int k) { return (j > k && j < 8) ? upi + slot[k] : up_tiles + slot[k]; };
+        if (u == 0 && i0 == 0) {
           sw0 = wave_column_swap<0>(b, j, det);
-          wave_pivot<6, 8, 0>(b, j, det, upi + 0, false);
+          wave_pivot<6, 8, 0, false>(b, det, slot_ptr(0));
           sw1 = wave_column_swap<1>(b, j, det);
-          wave_pivot<6, 8, 1>(b, j, det, upi + 7, false);
+          wave_pivot<6, 8, 1, false>(b, det, slot_ptr(1));
         } else {
-          wave_pivot<6, 8, 0>(b, j, det, upi + 0, true);
-          wave_pivot<6, 8, 1>(b, j, det, upi + 7, true);
+          wave_pivot<6, 8, 0, true>(b, det, slot_ptr(0));
+          wave_pivot<6, 8, 1, true>(b, det, slot_ptr(1));
         }
-        wave_pivot<6, 8, 2>(b, j, det, upi + 13, true);
-        wave_pivot<6, 8, 3>(b, j, det, upi + 18, true);
+        wave_pivot<6, 8, 2, true>(b, det, slot_ptr(2));
+        wave_pivot<6, 8, 3, true>(b, det, slot_ptr(3));
         // the two untouched rows move up: B[i][j] = B[i+4][j+4], right half cleared
-        const double t4 = __shfl_down(b[4], 4, 8), t5 = __shfl_down(b[5], 4, 8);
+        const double t4 = row_shift_left4(b[4]), t5 = row_shift_left4(b[5]);
         b[0] = (j < 4) ? t4 : 0.0;
         b[1] = (j < 4) ? t5 : 0.0;
       }
     }
+    buf ^= 1;
   }
-  if (j == 0) { swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1; }
+  if (n_int > 0) {
+    __syncthreads();
+    flush_factors((n_int - 1) / kEigBlock * kEigBlock, up_tiles + (buf ^ 1) * kEigUpTile);
+  }
+  if (lane == 0) { swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1; }
   // outer boundary rows (reference src/system/adiabatic.rs:185-208) and the closing 4x4
   b[2] = (j == 0) ? 1.0 : ((j == 1) ? -1.0 : 0.0);
   b[3] = (j == 0) ? s.outer_u : ((j == 2) ? s.ell + 1.0 : ((j == 3) ? 1.0 : 0.0));
   double* __restrict__ uf = up + n_int * 22;
-  wave_pivot<4, 4, 0>(b, j, det, uf + 0, true);
-  wave_pivot<4, 4, 1>(b, j, det, uf + 3, true);
-  wave_pivot<4, 4, 2>(b, j, det, uf + 5, true);
+  wave_pivot<4, 4, 0, true>(b, det, (j > 0 && j < 4) ? uf + 0 + j - 1 : dump + lane);
+  wave_pivot<4, 4, 1, true>(b, det, (j > 1 && j < 4) ? uf + 3 + j - 2 : dump + lane);
+  wave_pivot<4, 4, 2, true>(b, det, (j > 2 && j < 4) ? uf + 5 + j - 3 : dump + lane);
   const double last = lane_value(b[3], 3);
-  if (j == 0) det_out[m] = det * last;
+  if (lane == 0) det_out[m] = det * last;
 }
 
 // Back-substitution.  `upper` is walked backwards exactly like the reference's reversed
