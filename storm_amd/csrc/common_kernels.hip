@@ -304,17 +304,22 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
   if (lane == 0) det_out[m] = det * last;
 }
 
-// Back-substitution.  `upper` is walked backwards exactly like the reference's reversed
-// iterator; e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.
-// One wave per mode: all 64 lanes stream the packed factors of the next kBsTile intervals into LDS
-// (coalesced, one tile ahead of the consumer) and flush finished eigenvector components back out;
-// every lane runs the same short recurrence redundantly on wave-uniform data read from LDS, so no
-// cross-lane traffic sits on the serial chain.
-constexpr int kBsTile = 32;  // intervals per LDS tile
+// Back-substitution.  `upper` is walked backwards exactly like the reference's reversed iterator
+// (src/solver.rs:100-131); e[] is the eigenvector, length (n_int+1)*4, last component fixed to 1.
+// One wave per mode, every lane runs the same short recurrence (44 multiply/subtract instructions per interval) on
+// wave-uniform data.  The packed factors arrive kBsTile intervals (5.5 KB) at a time by LDS-DMA, one tile ahead; the
+// 22 factors of interval k-1 are read from LDS into registers while interval k is being computed, so neither global
+// nor LDS latency sits on the serial chain.  Finished components are parked in LDS (every lane writes the same
+// value) and flushed one tile at a time with coalesced stores.
+constexpr int kBsTile = 32;                    // intervals per tile
+constexpr int kBsTileDoubles = kBsTile * 22;   // 704 doubles = 5632 B = 5.5 DMA instructions
+constexpr int kBsTileStride = 6 * 128;         // doubles: room for the 6 whole DMA instructions of a tile
 
 __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
                                                            const int* __restrict__ swaps, double* __restrict__ vec) {
-  __shared__ double fac[2][kBsTile * 22];
+  // one shared object: two factor tiles + the parking area for finished components
+  __shared__ __attribute__((aligned(16))) double lds[2 * kBsTileStride + kBsTile * 4];
+  double* const park = lds + 2 * kBsTileStride;
   const size_t m = blockIdx.x;
   const int lane = threadIdx.x;
   const size_t ustride = n_int * 22 + 6;
@@ -329,54 +334,88 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
   const double e0 = ((0.0 - df[2] * e3) - df[1] * e2) - df[0] * e1;
   if (lane == 0) { e[len - 1] = e3; e[len - 2] = e2; e[len - 3] = e1; e[len - 4] = e0; }
   double b0 = e3, b1 = e2, b2 = e1, b3 = e0;
-  // tiles are taken from the END of the interval range: tile t covers intervals [hi - cnt, hi)
+  // tiles are taken from the END of the interval range: tile t covers intervals [hi - cnt, hi), hi = n_int - t*kBsTile
   const size_t n_tiles = (n_int + kBsTile - 1) / kBsTile;
   auto tile_bounds = [&](size_t t, size_t& lo, size_t& cnt) {
     const size_t hi = n_int - t * kBsTile;
     cnt = hi < (size_t)kBsTile ? hi : (size_t)kBsTile;
     lo = hi - cnt;
   };
-  auto load_tile = [&](size_t t, double* dst) {
+  const char* __restrict__ dbytes = reinterpret_cast<const char*>(d);
+  const size_t last_piece = n_int * 176 - 16;  // (n_int > 0 whenever this is used)
+  auto stage_tile = [&](size_t t, double* dst) {  // interval lo + q of the tile lands at dst[q*22 ...]
     size_t lo, cnt;
     tile_bounds(t, lo, cnt);
-    const double* src = d + lo * 22;
-    for (size_t q = lane; q < cnt * 22; q += 64) dst[q] = src[q];
-  };
-  if (n_tiles > 0) load_tile(0, fac[0]);
-  __syncthreads();
-  for (size_t t = 0; t < n_tiles; ++t) {
-    if (t + 1 < n_tiles) load_tile(t + 1, fac[(t + 1) & 1]);
-    size_t lo, cnt;
-    tile_bounds(t, lo, cnt);
-    const double* __restrict__ cur_tile = fac[t & 1];
-#pragma unroll 4
-    for (size_t k = cnt; k-- > 0;) {
-      const double* __restrict__ cur = cur_tile + k * 22;
-      // reversed iteration over this interval's 22 entries: row k=3 (4 entries, reversed), then
-      // row k=2 (5), k=1 (6), k=0 (7); the LAST stored entry of a row multiplies the newest-but-3 value.
-      double v0 = 0.0;
-      v0 = v0 - cur[21] * b0; v0 = v0 - cur[20] * b1; v0 = v0 - cur[19] * b2; v0 = v0 - cur[18] * b3;
-      double v1 = 0.0;
-      v1 = v1 - cur[17] * b0; v1 = v1 - cur[16] * b1; v1 = v1 - cur[15] * b2; v1 = v1 - cur[14] * b3;
-      v1 = v1 - cur[13] * v0;
-      double v2 = 0.0;
-      v2 = v2 - cur[12] * b0; v2 = v2 - cur[11] * b1; v2 = v2 - cur[10] * b2; v2 = v2 - cur[9] * b3;
-      v2 = v2 - cur[8] * v0; v2 = v2 - cur[7] * v1;
-      double v3 = 0.0;
-      v3 = v3 - cur[6] * b0; v3 = v3 - cur[5] * b1; v3 = v3 - cur[4] * b2; v3 = v3 - cur[3] * b3;
-      v3 = v3 - cur[2] * v0; v3 = v3 - cur[1] * v1; v3 = v3 - cur[0] * v2;
-      // components of grid point (lo + k): y1..y4 = v3, v2, v1, v0
-      if (lane == 0) {
-        double2* __restrict__ dst = reinterpret_cast<double2*>(e + (lo + k) * 4);
-        dst[0] = make_double2(v3, v2);
-        dst[1] = make_double2(v1, v0);
-      }
-      b0 = v0; b1 = v1; b2 = v2; b3 = v3;
+    static_assert((kBsTileDoubles * 8 + 1023) / 1024 * 128 <= kBsTileStride, "tile stride");
+#pragma unroll
+    for (int qd = 0; qd < (kBsTileDoubles * 8 + 1023) / 1024; ++qd) {
+      size_t off = lo * 176 + (size_t)qd * 1024 + (size_t)lane * 16;
+      off = off < last_piece ? off : last_piece;
+      __builtin_amdgcn_global_load_lds((eig_glb_ptr)(dbytes + off), (eig_lds_ptr)(dst + qd * 128), 16, 0, 0);
     }
-    __syncthreads();  // everyone is done with fac[t & 1] before it is refilled two tiles later
+  };
+  struct Factors { double2 v[11]; };
+  auto read_factors = [](const double* src) {
+    Factors f;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) f.v[q] = *reinterpret_cast<const double2*>(src + q * 2);
+    return f;
+  };
+  if (n_tiles > 0) stage_tile(0, lds);
+  for (size_t t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t (requested one tile ago) has landed
+    __syncthreads();
+    if (t + 1 < n_tiles) stage_tile(t + 1, lds + ((t + 1) & 1) * kBsTileStride);
+    size_t lo, cnt;
+    tile_bounds(t, lo, cnt);
+    const double* __restrict__ cur_tile = lds + (t & 1) * kBsTileStride;
+    // One interval.  Written so that the in-order issue of a lone wave is not held up by FP64 latency: first the 16
+    // products that only need the previous point (independent of each other), then the four partial sums side by
+    // side, then the short triangular tail that really is serial.  Same operations per component, same order of the
+    // subtractions within each component as the reference's reversed iterator.
+    auto interval = [&](const Factors& c, size_t k) {
+      // entry 2q, 2q+1 of the interval's 22 = c.v[q].x, .y
+      const double p00 = c.v[10].y * b0, p10 = c.v[8].y * b0, p20 = c.v[6].x * b0, p30 = c.v[3].x * b0;
+      const double p01 = c.v[10].x * b1, p11 = c.v[8].x * b1, p21 = c.v[5].y * b1, p31 = c.v[2].y * b1;
+      const double p02 = c.v[9].y * b2, p12 = c.v[7].y * b2, p22 = c.v[5].x * b2, p32 = c.v[2].x * b2;
+      const double p03 = c.v[9].x * b3, p13 = c.v[7].x * b3, p23 = c.v[4].y * b3, p33 = c.v[1].y * b3;
+      double v0 = 0.0 - p00, v1 = 0.0 - p10, v2 = 0.0 - p20, v3 = 0.0 - p30;
+      v0 = v0 - p01; v1 = v1 - p11; v2 = v2 - p21; v3 = v3 - p31;
+      v0 = v0 - p02; v1 = v1 - p12; v2 = v2 - p22; v3 = v3 - p32;
+      v0 = v0 - p03; v1 = v1 - p13; v2 = v2 - p23; v3 = v3 - p33;
+      const double q10 = c.v[6].y * v0, q20 = c.v[4].x * v0, q30 = c.v[1].x * v0;
+      v1 = v1 - q10; v2 = v2 - q20; v3 = v3 - q30;
+      const double q21 = c.v[3].y * v1, q31 = c.v[0].y * v1;
+      v2 = v2 - q21; v3 = v3 - q31;
+      v3 = v3 - c.v[0].x * v2;
+      // components of grid point (lo + k): y1..y4 = v3, v2, v1, v0 (all lanes hold the same values)
+      double2* __restrict__ dst = reinterpret_cast<double2*>(park + k * 4);
+      dst[0] = make_double2(v3, v2);
+      dst[1] = make_double2(v1, v0);
+      b0 = v0; b1 = v1; b2 = v2; b3 = v3;
+    };
+    // two register sets take turns (no copies): while one interval is computed the next one's factors are in flight
+    Factors fa = read_factors(cur_tile + (cnt - 1) * 22), fb;
+    size_t k = cnt;
+    while (k >= 2) {
+      fb = read_factors(cur_tile + (k - 2) * 22);
+      interval(fa, k - 1);
+      if (k >= 3) fa = read_factors(cur_tile + (k - 3) * 22);
+      interval(fb, k - 2);
+      k -= 2;
+    }
+    if (k == 1) interval(fa, 0);
+    __syncthreads();
+#pragma unroll
+    for (int qd = 0; qd < kBsTile * 4 / 64; ++qd) {
+      const size_t at = (size_t)qd * 64 + lane;
+      if (at < cnt * 4) e[lo * 4 + at] = park[at];
+    }
   }
   // undo the column pivots of the first interval, last recorded first
+  __syncthreads();
   if (lane == 0) {
+    __threadfence_block();
     const int s1 = swaps[m * 2 + 1], s0 = swaps[m * 2 + 0];
     if (s1 != 1) { const double a = e[s1], b = e[1]; e[s1] = b; e[1] = a; }
     if (s0 != 0) { const double a = e[s0], b = e[0]; e[s0] = b; e[0] = a; }
