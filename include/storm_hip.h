@@ -176,6 +176,46 @@ int storm_coupling_matrices(storm_postproc* post, size_t n, const uint64_t* ell,
  * on this handle; measurement aid, no counterpart in the reference. */
 double storm_postproc_last_kernel_ms(const storm_postproc* post);
 
+/* ---- Several systems per launch: rotation sweeps ----
+ *
+ * Replaces the reference's one-solver-per-`scan`-line loop for batch inputs that sweep many (ell, m, rotation rate)
+ * systems with scans of only 100-300 frequencies each (scripts/generate-batch-input-deformed.py:19-35; each `scan`
+ * builds get_solvers_inner_explicit + ErasedSolver::scan_and_optimize, src/main.rs:815-831,
+ * src/dynamic_interface.rs:116-160,193-221).  One such scan cannot fill a GPU, so a storm_sweep runs S systems in
+ * lock-step: one discriminant launch over every (system, frequency) pair, the refinement rounds of all systems
+ * merged, one eigenvector launch over all modes.  Results are bit-identical to S separate storm_solver handles.
+ *
+ * All systems share the difference scheme and n_int (the grid); ell, m and every coefficient array may differ.
+ * Per-system lists are passed concatenated with CSR-style offsets: system u owns entries
+ * [offsets[u], offsets[u+1]) of the arrays, offsets has n_sys + 1 entries, offsets[0] = 0.  Host pointers. */
+typedef struct storm_sweep storm_sweep;
+int storm_sweep_create(const storm_system_desc* descs, size_t n_sys, storm_sweep** out);
+void storm_sweep_destroy(storm_sweep* sweep);
+size_t storm_sweep_size(const storm_sweep* sweep);  /* n_sys */
+size_t storm_sweep_n_int(const storm_sweep* sweep);
+
+/* storm_det_batch for every system: det_out[i] = det_u(freq[i]) for i in system u's range. */
+int storm_sweep_det(storm_sweep* sweep, const size_t* offsets, const double* freq, double* det_out);
+
+/* storm_scan_and_optimize for every system.  out receives the brackets of system u at
+ * [out_offsets[u], out_offsets[u+1]) (out_offsets: n_sys + 1 entries, written by the call; if the total exceeds cap the
+ * call fails with STORM_ERR_CAPACITY after filling out_offsets, so the caller can size `out` and call again).
+ * had_invalid (may be NULL) has n_sys entries; det_out (may be NULL) is laid out like freq; index_out (may be NULL,
+ * cap entries) holds each bracket's lower grid index inside its own system's scan. */
+int storm_sweep_scan_and_optimize(storm_sweep* sweep, const size_t* freq_offsets, const double* freq, uint64_t ulp,
+                                  storm_bracket* out, size_t cap, size_t* out_offsets, int* had_invalid,
+                                  double* det_out, uint64_t* index_out);
+
+/* storm_eigenvector_batch for every system: vec_out [total modes][(n_int+1)*4] in the order of freq. */
+int storm_sweep_eigenvectors(storm_sweep* sweep, const size_t* offsets, const double* freq, double* det_out,
+                             double* vec_out);
+
+/* storm_modes_batch for every system; posts[u] is the post-processing handle (model) of system u (handles may
+ * repeat; entries of systems without modes may be NULL).  det_out, vec_out, fields_out, nodes_out may each be NULL. */
+int storm_sweep_modes(storm_sweep* sweep, storm_postproc* const* posts, const size_t* offsets, const double* freq,
+                      double* det_out, double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out,
+                      size_t node_cap);
+
 /* ---- Memory cache (no counterpart in the reference) ----
  * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
  * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent
@@ -217,6 +257,10 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *   "fused_min_n": batch size from which "path" 0 picks the fused kernel
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
+
+/* Counters and options of a sweep ("arithmetic", "hex_lanes", "steps_bytes_max" as below). */
+int storm_sweep_stats(storm_sweep* sweep, storm_stats* out, int reset);
+int storm_sweep_set_option(storm_sweep* sweep, const char* key, int64_t value);
 
 size_t storm_solver_n_int(const storm_solver* solver);
 

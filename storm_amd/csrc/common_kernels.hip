@@ -188,10 +188,12 @@ typedef __attribute__((address_space(3))) void* eig_lds_ptr;
 typedef __attribute__((address_space(1))) const void* eig_glb_ptr;
 
 template <bool ELL0>
-__global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+__global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
                                                            const double* __restrict__ steps,
                                                            double* __restrict__ upper, int* __restrict__ swaps,
-                                                           double* __restrict__ det_out) {
+                                                           double* __restrict__ det_out,
+                                                           const SystemDev* __restrict__ table,
+                                                           const int* __restrict__ sys_index) {
   // one shared object (a second one beside an LDS-DMA target makes hipcc drain the DMA before every LDS read)
   __shared__ __attribute__((aligned(16))) double lds[2 * kEigStepTile + 2 * kEigUpTile + 64];
   double* const up_tiles = lds + 2 * kEigStepTile;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s, const do
   const int lane = threadIdx.x;
   const int j = lane;          // lanes 0..7 carry the band; the others idle along (their values are never used)
   const size_t m = blockIdx.x;  // one wave per mode
+  const SystemDev s = table ? table[sys_index[m]] : s0;  // several systems per launch: see LaunchArgs in types.hpp
   const double f = freq[m];
   const size_t n_int = s.n_int;
   const size_t ustride = n_int * 22 + 6;
@@ -423,11 +426,12 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
 }
 
 hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
-                        double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream) {
+                        double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream,
+                        const SystemDev* table, const int* sys_index) {
   if (n == 0) return hipSuccess;
   const unsigned fblocks = (unsigned)n;  // one wave per mode
-  if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
-  else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out);
+  if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+  else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   eigen_backsub_kernel<<<(unsigned)n, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);

@@ -200,6 +200,87 @@ int storm_host_modes(void* p, void* solver, const double* roots, size_t n, int w
   });
 }
 
+// ---- SolverSweep: per-system lists arrive concatenated with offsets [n_sys + 1] ----
+namespace {
+std::vector<std::vector<double>> split(const size_t* off, const double* f, size_t n_sys) {
+  std::vector<std::vector<double>> lists(n_sys);
+  for (size_t u = 0; u < n_sys; ++u) lists[u].assign(f + off[u], f + off[u + 1]);
+  return lists;
+}
+}  // namespace
+
+void* storm_host_sweep_new(void* const* models, const uint64_t* ell, const int64_t* mm, size_t n_sys, int scheme,
+                           const double* grid, size_t ngrid) {
+  SolverSweep* s = nullptr;
+  if (guarded([&] {
+        if (scheme < 0 || scheme > 7) throw std::runtime_error("unknown difference scheme");
+        // one continuous model per distinct handle, so systems sharing a model share its interpolation
+        std::vector<void*> distinct;
+        std::vector<std::unique_ptr<ContinuousModel>> cms;
+        std::vector<SweepSystem> systems(n_sys);
+        for (size_t u = 0; u < n_sys; ++u) {
+          size_t at = 0;
+          while (at < distinct.size() && distinct[at] != models[u]) ++at;
+          if (at == distinct.size()) { distinct.push_back(models[u]); cms.push_back(static_cast<HostModel*>(models[u])->continuous()); }
+          systems[u] = SweepSystem{cms[at].get(), Rotating1D::make(ell[u], mm[u])};
+        }
+        s = new SolverSweep(systems, DifferenceSchemes(scheme), std::vector<double>(grid, grid + ngrid));
+      })) return nullptr;
+  return s;
+}
+void storm_host_sweep_free(void* s) { delete static_cast<SolverSweep*>(s); }
+size_t storm_host_sweep_len(void* s) { return static_cast<SolverSweep*>(s)->len(); }
+void* storm_host_sweep_handle(void* s) { return static_cast<SolverSweep*>(s)->handle(); }
+
+int storm_host_sweep_det(void* s, const size_t* off, const double* f, double* out) {
+  SolverSweep* sw = static_cast<SolverSweep*>(s);
+  return guarded([&] {
+    const auto r = sw->det(split(off, f, sw->size()));
+    for (size_t u = 0; u < sw->size(); ++u) std::memcpy(out + off[u], r[u].data(), r[u].size() * sizeof(double));
+  });
+}
+int storm_host_sweep_scan_and_optimize(void* s, const size_t* off, const double* f, int precision_kind,
+                                       uint64_t precision_ulp, double precision_rel, storm_bracket* out, size_t cap,
+                                       size_t* out_off, int* had_invalid) {
+  SolverSweep* sw = static_cast<SolverSweep*>(s);
+  return guarded([&] {
+    const Precision prec = precision_kind == 0 ? Precision::ULP(precision_ulp) : Precision::Relative(precision_rel);
+    std::vector<bool> inv;
+    const auto r = sw->scan_and_optimize(split(off, f, sw->size()), prec, &inv);
+    out_off[0] = 0;
+    for (size_t u = 0; u < sw->size(); ++u) {
+      out_off[u + 1] = out_off[u] + r[u].size();
+      if (had_invalid) had_invalid[u] = inv[u] ? 1 : 0;
+      for (size_t k = 0; k < r[u].size(); ++k)
+        if (out_off[u] + k < cap) {
+          const BracketResult& b = r[u][k];
+          out[out_off[u] + k] = storm_bracket{b.lower.x, b.lower.f, b.upper.x, b.upper.f, b.root, b.evals};
+        }
+    }
+  });
+}
+int storm_host_sweep_eigenvectors(void* s, const size_t* off, const double* f, double* out) {
+  SolverSweep* sw = static_cast<SolverSweep*>(s);
+  return guarded([&] {
+    const size_t len = (sw->len() + 1) * 4;
+    const auto r = sw->eigenvectors(split(off, f, sw->size()));
+    for (size_t u = 0; u < sw->size(); ++u) std::memcpy(out + off[u] * len, r[u].data(), r[u].size() * sizeof(double));
+  });
+}
+int storm_host_sweep_modes(void* s, void* const* posts, const size_t* off, const double* f, int want_fields,
+                           double* fields_out, int64_t* ids_out, uint64_t* n_nodes_out, double* nodes_out, size_t node_cap) {
+  SolverSweep* sw = static_cast<SolverSweep*>(s);
+  return guarded([&] {
+    std::vector<const PostProcessor*> pp(sw->size());
+    for (size_t u = 0; u < sw->size(); ++u) pp[u] = static_cast<const PostProcessor*>(posts[u]);
+    const auto r = sw->modes(pp, split(off, f, sw->size()), want_fields != 0);
+    const size_t np = sw->len() + 1;
+    for (size_t u = 0; u < sw->size(); ++u)
+      flatten(r[u], np, want_fields ? fields_out + off[u] * STORM_POST_FIELDS * np : nullptr, ids_out + off[u] * 3,
+              n_nodes_out + off[u], nodes_out ? nodes_out + off[u] * node_cap : nullptr, node_cap);
+  });
+}
+
 // perturb_structure through the mirror: out6 = alpha, dalpha, ddalpha, beta, dbeta, ddbeta (each [n_pts]).
 int storm_host_perturb_structure(void* m, double rot, double* const* out6, double* mass_delta) {
   return guarded([&] {

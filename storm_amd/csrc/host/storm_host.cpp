@@ -1,6 +1,12 @@
 // storm_host.cpp -- see storm_host.hpp.  Built with -ffp-contract=off.
 #include "storm_host.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
+
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -260,40 +266,57 @@ void abscissae(DifferenceSchemes scheme, std::vector<double>& out) {  // Stepper
 }
 }  // namespace
 
+namespace {
+// What DiscretizedSystemImpl::new (discretized.rs:81-123) keeps of the model: the arrays behind one storm_system_desc.
+struct SystemArrays {
+  std::vector<double> u, vg, as, c1, rot, dx;
+  double inner_c1 = 0., inner_rot = 0., outer_u = 0.;
+  size_t steps = 0, p = 0;
+  SystemArrays(const ContinuousModel& model, DifferenceSchemes scheme, const std::vector<double>& grid) {
+    if (grid.empty()) throw std::runtime_error("ErasedSolver::new: empty solver grid");
+    std::vector<double> loc;
+    abscissae(scheme, loc);
+    p = loc.size(); steps = grid.size() - 1;
+    // discretized.rs:94-100
+    std::vector<double> delta(steps), xs(steps * p);
+    for (size_t i = 0; i < steps; ++i) delta[i] = grid[i + 1] - grid[i];
+    for (size_t i = 0; i < steps; ++i)
+      for (size_t j = 0; j < p; ++j) xs[i * p + j] = grid[i] + loc[j] * delta[i];
+    dx.resize(steps * p);
+    if (steps) {
+      const DiscreteModel at = model.eval(xs);
+      const DimensionlessProperties& d = at.dimensionless;
+      u = d.u; as = d.a_star; c1 = d.c1; rot = d.rot;
+      vg.resize(steps * p);
+      for (size_t k = 0; k < steps * p; ++k) vg[k] = d.v[k] / d.gamma1[k];  // adiabatic.rs:52
+      for (size_t i = 0; i < steps; ++i)
+        for (size_t j = 0; j < p; ++j) dx[i * p + j] = delta[i] / xs[i * p + j];
+    }
+    const DiscreteModel in = model.eval({model.inner()}), outm = model.eval({model.outer()});  // discretized.rs:119-120
+    inner_c1 = in.dimensionless.c1[0];
+    inner_rot = in.dimensionless.rot[0];
+    outer_u = outm.dimensionless.u[0];
+  }
+  storm_system_desc desc(Rotating1D system, DifferenceSchemes scheme) const {
+    storm_system_desc d{};
+    d.scheme = int32_t(scheme);
+    d.ell = system.ell; d.m = system.m;
+    d.n_int = steps; d.p = p;
+    d.u = u.data(); d.v_gamma = vg.data(); d.a_star = as.data(); d.c1 = c1.data();
+    d.rot = rot.data(); d.delta_over_x = dx.data();
+    d.inner_c1 = inner_c1; d.inner_rot = inner_rot; d.outer_u = outer_u;
+    return d;
+  }
+};
+}  // namespace
+
 ErasedSolver::ErasedSolver(const ContinuousModel& model, Rotating1D system, DifferenceSchemes scheme,
                            const std::vector<double>& grid) {
-  if (grid.empty()) throw std::runtime_error("ErasedSolver::new: empty solver grid");
-  std::vector<double> loc;
-  abscissae(scheme, loc);
-  const size_t p = loc.size(), steps = grid.size() - 1;
-  // DiscretizedSystemImpl::new, discretized.rs:94-100
-  std::vector<double> delta(steps), xs(steps * p);
-  for (size_t i = 0; i < steps; ++i) delta[i] = grid[i + 1] - grid[i];
-  for (size_t i = 0; i < steps; ++i)
-    for (size_t j = 0; j < p; ++j) xs[i * p + j] = grid[i] + loc[j] * delta[i];
-  std::vector<double> u, vg, as, c1, rot, dx(steps * p);
-  if (steps) {
-    const DiscreteModel at = model.eval(xs);
-    const DimensionlessProperties& d = at.dimensionless;
-    u = d.u; as = d.a_star; c1 = d.c1; rot = d.rot;
-    vg.resize(steps * p);
-    for (size_t k = 0; k < steps * p; ++k) vg[k] = d.v[k] / d.gamma1[k];  // adiabatic.rs:52
-    for (size_t i = 0; i < steps; ++i)
-      for (size_t j = 0; j < p; ++j) dx[i * p + j] = delta[i] / xs[i * p + j];
-  }
-  const DiscreteModel in = model.eval({model.inner()}), outm = model.eval({model.outer()});  // discretized.rs:119-120
-  storm_system_desc desc{};
-  desc.scheme = int32_t(scheme);
-  desc.ell = system.ell; desc.m = system.m;
-  desc.n_int = steps; desc.p = p;
-  desc.u = u.data(); desc.v_gamma = vg.data(); desc.a_star = as.data(); desc.c1 = c1.data();
-  desc.rot = rot.data(); desc.delta_over_x = dx.data();
-  desc.inner_c1 = in.dimensionless.c1[0];
-  desc.inner_rot = in.dimensionless.rot[0];
-  desc.outer_u = outm.dimensionless.u[0];
+  const SystemArrays arrays(model, scheme, grid);
+  const storm_system_desc desc = arrays.desc(system, scheme);
   const int rc = storm_solver_create(&desc, &h_);
   if (rc != STORM_OK) raise_abi("storm_solver_create", rc);
-  n_int_ = steps;
+  n_int_ = arrays.steps;
 }
 
 ErasedSolver::~ErasedSolver() { storm_solver_destroy(h_); }
@@ -350,6 +373,133 @@ std::vector<Solution> scan(const ContinuousModel& model, const std::vector<doubl
   for (size_t k = 0; k < res.size(); ++k)
     out[k] = Solution{res[k], std::vector<double>(vecs.begin() + k * len, vecs.begin() + (k + 1) * len), ell, m};
   return out;
+}
+
+// ---- SolverSweep: many systems in lock-step (storm_sweep) ----
+SolverSweep::SolverSweep(const std::vector<SweepSystem>& systems, DifferenceSchemes scheme,
+                         const std::vector<double>& grid) {
+  if (systems.empty()) throw std::runtime_error("SolverSweep: no systems");
+  // the model enters through its values at the collocation abscissae only: systems that share a model (the 8 (ell, m)
+  // of one rotation rate) share the interpolation
+  std::vector<const ContinuousModel*> distinct;
+  std::vector<size_t> which(systems.size());
+  for (size_t k = 0; k < systems.size(); ++k) {
+    if (!systems[k].model) throw std::runtime_error("SolverSweep: null model");
+    size_t at = 0;
+    while (at < distinct.size() && distinct[at] != systems[k].model) ++at;
+    if (at == distinct.size()) distinct.push_back(systems[k].model);
+    which[k] = at;
+  }
+  std::vector<std::unique_ptr<SystemArrays>> arrays(distinct.size());
+  {
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto work = [&] {
+      for (size_t k; (k = next.fetch_add(1)) < distinct.size();) {
+        try { arrays[k] = std::make_unique<SystemArrays>(*distinct[k], scheme, grid); }
+        catch (...) { std::lock_guard<std::mutex> lock(err_mu); if (!err) err = std::current_exception(); }
+      }
+    };
+    const size_t n_thr = std::min<size_t>({distinct.size(), size_t(std::max(1u, std::thread::hardware_concurrency())), size_t(16)});
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+  }
+  std::vector<storm_system_desc> descs(systems.size());
+  for (size_t k = 0; k < systems.size(); ++k) {
+    descs[k] = arrays[which[k]]->desc(systems[k].system, scheme);
+    ell_.push_back(systems[k].system.ell); m_.push_back(systems[k].system.m);
+  }
+  const int rc = storm_sweep_create(descs.data(), descs.size(), &h_);
+  if (rc != STORM_OK) raise_abi("storm_sweep_create", rc);
+  n_int_ = arrays[0]->steps;
+}
+SolverSweep::~SolverSweep() { storm_sweep_destroy(h_); }
+
+namespace {
+std::vector<size_t> flatten(const std::vector<std::vector<double>>& lists, size_t n_sys, std::vector<double>& flat) {
+  if (lists.size() != n_sys) throw std::runtime_error("SolverSweep: one list per system expected");
+  std::vector<size_t> off(n_sys + 1, 0);
+  for (size_t u = 0; u < n_sys; ++u) off[u + 1] = off[u] + lists[u].size();
+  flat.resize(off[n_sys]);
+  for (size_t u = 0; u < n_sys; ++u) std::copy(lists[u].begin(), lists[u].end(), flat.begin() + off[u]);
+  return off;
+}
+}  // namespace
+
+std::vector<std::vector<double>> SolverSweep::det(const std::vector<std::vector<double>>& freqs) const {
+  std::vector<double> flat;
+  const std::vector<size_t> off = flatten(freqs, size(), flat);
+  std::vector<double> out(flat.size());
+  const int rc = storm_sweep_det(h_, off.data(), flat.data(), out.data());
+  if (rc != STORM_OK) raise_abi("storm_sweep_det", rc);
+  std::vector<std::vector<double>> res(size());
+  for (size_t u = 0; u < size(); ++u) res[u].assign(out.begin() + off[u], out.begin() + off[u + 1]);
+  return res;
+}
+
+std::vector<std::vector<BracketResult>> SolverSweep::scan_and_optimize(const std::vector<std::vector<double>>& grids,
+                                                                       Precision precision,
+                                                                       std::vector<bool>* had_invalid) const {
+  std::vector<double> flat;
+  const std::vector<size_t> off = flatten(grids, size(), flat);
+  std::vector<storm_bracket> raw(flat.size() ? flat.size() : 1);
+  std::vector<size_t> ooff(size() + 1, 0);
+  std::vector<int> inv(size(), 0);
+  const int rc = storm_sweep_scan_and_optimize(h_, off.data(), flat.data(), precision.as_ulp(), raw.data(), raw.size(),
+                                               ooff.data(), inv.data(), nullptr, nullptr);
+  if (rc != STORM_OK) raise_abi("storm_sweep_scan_and_optimize", rc);
+  if (had_invalid) { had_invalid->assign(size(), false); for (size_t u = 0; u < size(); ++u) (*had_invalid)[u] = inv[u] != 0; }
+  std::vector<std::vector<BracketResult>> res(size());
+  for (size_t u = 0; u < size(); ++u)
+    for (size_t k = ooff[u]; k < ooff[u + 1]; ++k)
+      res[u].push_back(BracketResult{Point{raw[k].lo_x, raw[k].lo_f}, Point{raw[k].hi_x, raw[k].hi_f}, raw[k].root, raw[k].evals});
+  return res;
+}
+
+std::vector<std::vector<double>> SolverSweep::eigenvectors(const std::vector<std::vector<double>>& roots) const {
+  std::vector<double> flat;
+  const std::vector<size_t> off = flatten(roots, size(), flat);
+  const size_t len = (n_int_ + 1) * 4;
+  std::vector<double> out(flat.size() * len);
+  const int rc = storm_sweep_eigenvectors(h_, off.data(), flat.data(), nullptr, out.data());
+  if (rc != STORM_OK) raise_abi("storm_sweep_eigenvectors", rc);
+  std::vector<std::vector<double>> res(size());
+  for (size_t u = 0; u < size(); ++u) res[u].assign(out.begin() + off[u] * len, out.begin() + off[u + 1] * len);
+  return res;
+}
+
+std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes(const std::vector<const PostProcessor*>& posts,
+                                                                      const std::vector<std::vector<double>>& roots,
+                                                                      bool want_fields) const {
+  if (posts.size() != size()) throw std::runtime_error("SolverSweep::modes: one PostProcessor per system expected");
+  std::vector<double> flat;
+  const std::vector<size_t> off = flatten(roots, size(), flat);
+  const size_t n = flat.size(), np = n_int_ + 1;
+  std::vector<storm_postproc*> handles(size(), nullptr);
+  for (size_t u = 0; u < size(); ++u) {
+    if (!posts[u] && off[u + 1] > off[u]) throw std::runtime_error("SolverSweep::modes: null PostProcessor");
+    if (posts[u]) handles[u] = posts[u]->handle();
+  }
+  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes(n * np);
+  std::vector<storm_mode_id> ids(n ? n : 1);
+  const int rc = storm_sweep_modes(h_, handles.data(), off.data(), flat.data(), nullptr, nullptr,
+                                   want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), np);
+  if (rc != STORM_OK) raise_abi("storm_sweep_modes", rc);
+  std::vector<std::vector<Rotating1DPostprocessing>> res(size());
+  for (size_t u = 0; u < size(); ++u) {
+    const size_t a = off[u], cnt = off[u + 1] - off[u];
+    if (!cnt) continue;
+    const std::vector<double> f(want_fields ? fields.begin() + a * STORM_POST_FIELDS * np : fields.begin(),
+                                want_fields ? fields.begin() + (a + cnt) * STORM_POST_FIELDS * np : fields.begin());
+    const std::vector<storm_mode_id> id(ids.begin() + a, ids.begin() + a + cnt);
+    const std::vector<double> nd(nodes.begin() + a * np, nodes.begin() + (a + cnt) * np);
+    res[u] = posts[u]->unpack(cnt, f, id, nd, np);
+  }
+  return res;
 }
 
 // ---- post-processing ----

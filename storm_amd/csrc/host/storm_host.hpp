@@ -187,6 +187,8 @@ struct CouplingMatrices {
   double at(const std::vector<double>& mat, size_t left, size_t right) const { return mat[left + right * n]; }
 };
 
+class SolverSweep;
+
 // The model arrays of the post-processing resident on the device (storm_postproc).
 class PostProcessor {
  public:
@@ -205,11 +207,48 @@ class PostProcessor {
   storm_postproc* handle() const { return h_; }
 
  private:
+  friend class SolverSweep;
   std::vector<Rotating1DPostprocessing> unpack(size_t n, const std::vector<double>& fields,
                                                const std::vector<storm_mode_id>& ids, const std::vector<double>& nodes,
                                                size_t node_cap) const;
   storm_postproc* h_ = nullptr;
   std::vector<double> x_;
+};
+
+// Many systems evaluated in lock-step (storm_sweep): what a batch input that sweeps rotation rates and (ell, m) does
+// with one ErasedSolver per `scan` line (main.rs:815-831, scripts/generate-batch-input-deformed.py:19-35), as one
+// object.  All systems share the difference scheme and the solver grid; the model, ell and m may differ.  Results are
+// bit-identical to one ErasedSolver per system.  Per-system inputs and outputs are vectors indexed by system.
+struct SweepSystem {
+  const ContinuousModel* model;  // borrowed for the constructor only; systems may share one
+  Rotating1D system;
+};
+class SolverSweep {
+ public:
+  SolverSweep(const std::vector<SweepSystem>& systems, DifferenceSchemes scheme, const std::vector<double>& solver_grid);
+  ~SolverSweep();
+  SolverSweep(const SolverSweep&) = delete;
+  SolverSweep& operator=(const SolverSweep&) = delete;
+
+  std::vector<std::vector<double>> det(const std::vector<std::vector<double>>& freqs) const;
+  std::vector<std::vector<BracketResult>> scan_and_optimize(const std::vector<std::vector<double>>& freq_grids,
+                                                            Precision precision,
+                                                            std::vector<bool>* had_invalid_numbers = nullptr) const;
+  // per system: row-major [modes][(n_int+1)*4]
+  std::vector<std::vector<double>> eigenvectors(const std::vector<std::vector<double>>& roots) const;
+  // eigenvectors + post-processing on the device; posts[u] = the model of system u on the solver grid
+  std::vector<std::vector<Rotating1DPostprocessing>> modes(const std::vector<const PostProcessor*>& posts,
+                                                           const std::vector<std::vector<double>>& roots,
+                                                           bool want_fields) const;
+  size_t size() const { return ell_.size(); }
+  size_t len() const { return n_int_; }
+  storm_sweep* handle() const { return h_; }
+
+ private:
+  storm_sweep* h_ = nullptr;
+  size_t n_int_ = 0;
+  std::vector<uint64_t> ell_;
+  std::vector<int64_t> m_;
 };
 
 }  // namespace storm_host

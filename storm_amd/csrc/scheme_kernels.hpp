@@ -178,8 +178,9 @@ SDEV void hex_stage_coefficients(const SystemDev& s, size_t i0, double* tile, in
 }
 
 template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
-__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
-                                                     double* __restrict__ det_out, int* __restrict__ flags) {
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
+                                                     double* __restrict__ det_out, int* __restrict__ flags,
+                                                     const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
   static_assert(LPF == 16 || LPF == 32 || LPF == 64, "lanes per frequency");
   constexpr int kFreqs = 64 / LPF;  // frequencies per wave
   constexpr int kGroup = hex_group_stride(LPF);
@@ -198,6 +199,8 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   const int r = e & 3;
   const int c = e >> 2;
   const size_t t = (size_t)blockIdx.x * kFreqs + g;
+  // the wave's system: its own when several systems share the launch (wave-uniform, read through the scalar unit)
+  const SystemDev s = table ? table[sys_index[(size_t)blockIdx.x * kFreqs]] : s0;
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
@@ -265,12 +268,14 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 }
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
-__global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
-                                                          double* __restrict__ steps, int* __restrict__ flags) {
+__global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
+                                                          double* __restrict__ steps, int* __restrict__ flags,
+                                                          const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
   // grid.x covers intervals in tiles of 256, grid.y = frequency
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t fi = blockIdx.y;
   if (fi >= n) return;
+  const SystemDev s = table ? table[sys_index[fi]] : s0;
   const double f = freq[fi];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   if (i >= s.n_int) return;

@@ -48,7 +48,7 @@ static double hex_cost(size_t n, size_t n_int) {
 template <bool ELL0, bool UNIFORM, int LPF>
 static hipError_t launch_hex_lpf(const LaunchArgs& a) {
   const unsigned blocks = (unsigned)((a.n * LPF + 63) / 64);
-  det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
+  det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags, a.table, a.sys_index);
   return hipGetLastError();
 }
 template <bool ELL0, bool UNIFORM>
@@ -61,7 +61,7 @@ static hipError_t launch_hex_v(const LaunchArgs& a) {
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_build_v(const LaunchArgs& a) {
   const dim3 grid((unsigned)((a.sys.n_int + 255) / 256), (unsigned)a.n, 1);
-  build_steps_kernel<STORM_SCHEME, ELL0, UNIFORM><<<grid, 256, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
+  build_steps_kernel<STORM_SCHEME, ELL0, UNIFORM><<<grid, 256, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags, a.table, a.sys_index);
   return hipGetLastError();
 }
 

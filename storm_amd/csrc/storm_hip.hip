@@ -6,6 +6,8 @@
 // point fails with STORM_ERR_HIP.
 #include "../../include/storm_hip.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -13,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common_kernels.hpp"
@@ -286,9 +289,12 @@ int guarded(F&& f) {
 // Host arithmetic here is un-fused (this file is built with -ffp-contract=off).
 size_t padded_stride(size_t n_int) { return (n_int + 63) / 64 * 64 + 64; }
 
-void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& uniform, double& rotm0) {
+size_t planes_elems(size_t n_int, size_t p) { return padded_stride(n_int) * p * kNumFields; }
+
+// `t`: planes_elems(d.n_int, d.p) doubles.
+void build_planes(const storm_system_desc& d, double* t, bool& uniform, double& rotm0) {
   const size_t n_int = d.n_int, p = d.p, stride = padded_stride(n_int), plane = stride * p;
-  tab.assign(plane * kNumFields, 0.0);
+  std::memset(t, 0, plane * kNumFields * sizeof(double));
   const double ell = double(d.ell), mm = double(d.m);
   const double lambda = ell * (ell + 1.0);
   uniform = true;
@@ -299,7 +305,6 @@ void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& un
     for (size_t j = 0; j < p; ++j) {
       const size_t src = i * p + j, dst = j * stride + i;
       const double dx = d.delta_over_x[src], u = d.u[src], vg = d.v_gamma[src], as = d.a_star[src];
-      double* t = tab.data();
       t[F_M00 * plane + dst] = dx * (vg - 1.0 - ell);
       t[F_M01 * plane + dst] = -dx * vg;
       t[F_M10 * plane + dst] = -dx * as;
@@ -323,12 +328,19 @@ void build_planes(const storm_system_desc& d, std::vector<double>& tab, bool& un
   if (n_int)
     for (size_t fld = 0; fld < size_t(kNumFields); ++fld)
       for (size_t j = 0; j < p; ++j) {
-        double* row = tab.data() + fld * plane + j * stride;
+        double* row = t + fld * plane + j * stride;
         for (size_t i = n_int; i < stride; ++i) row[i] = row[n_int - 1];
       }
 }
 
 void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
+
+// The pinned staging block also carried the planes to the device in storm_solver_create: before it can go back to
+// the cache that upload (or an earlier result copy) must have finished.
+void stage_reserve(storm_solver* s, size_t n) {
+  if (n > s->h_vec.cap && s->h_vec.p) hip_check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+  s->h_vec.reserve(n);
+}
 
 hipEvent_t take_event(storm_solver* s) {
   if (!s->event_pool.empty()) { hipEvent_t e = s->event_pool.back(); s->event_pool.pop_back(); return e; }
@@ -558,7 +570,7 @@ void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
   tb.stop();
   ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
   hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
-                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream), "eigen launch");
+                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream, nullptr, nullptr), "eigen launch");
   te.stop();
   count_launch(s, 3);
   s->stats.eigenvectors += m;
@@ -707,25 +719,22 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     s = new storm_solver();
     hip_check(hipGetDevice(&s->device), "hipGetDevice");
     s->scheme = d->scheme;
-    std::vector<double> tab;
     double rotm0 = 0.0;
-    build_planes(*d, tab, s->uniform, rotm0);
+    const size_t tab_elems = planes_elems(d->n_int, d->p);
+    s->h_vec.reserve(tab_elems);  // built in the (cached) pinned block the upload is staged from
+    build_planes(*d, s->h_vec.p, s->uniform, rotm0);
     const double ell = double(d->ell);
     s->ell0 = (ell == 0.0);
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
-    s->tab.reserve(tab.size() ? tab.size() : 1, nullptr);
+    s->tab.reserve(tab_elems, nullptr);
     s->stream = MemoryCache::get().take_stream(s->device);
     // Uploads are ordered on the solver's own (non-blocking) stream: a plain hipMemcpy from pageable
     // memory is only ordered against the NULL stream, so a kernel launched on s->stream right after
     // create could otherwise read the planes before the DMA has landed.
     // (staged through a cached pinned buffer: a copy from pageable memory goes through the runtime's own staging
     // path, which serialises concurrent creates)
-    if (!tab.empty()) {
-      s->h_vec.reserve(tab.size());
-      std::memcpy(s->h_vec.p, tab.data(), tab.size() * sizeof(double));
-      hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, tab.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
-                "planes H2D");
-    }
+    hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, tab_elems * sizeof(double), hipMemcpyHostToDevice, s->stream),
+              "planes H2D");
     s->d_flags.reserve(1);
     hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags memset");
     // no wait: every later kernel of this handle runs on the same stream, behind the upload; the pinned staging
@@ -895,7 +904,7 @@ int storm_eigenvector_batch(storm_solver* s, const double* freq, size_t n, doubl
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
       eigen_chunk(s, freq + off, m);
-      s->h_vec.reserve(m * len);
+      stage_reserve(s, m * len);
       hip_check(hipMemcpyAsync(s->h_vec.p, s->d_vec.p, m * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
       if (det_out)
         hip_check(hipMemcpyAsync(det_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, s->stream), "det D2H");
@@ -1121,7 +1130,7 @@ int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, si
       tp.stop();
       count_launch(s, fields_out ? 3 : 2);
       if (vec_out) {
-        s->h_vec.reserve(k * len);
+        stage_reserve(s, k * len);
         hip_check(hipMemcpyAsync(s->h_vec.p, s->d_vec.p, k * len * sizeof(double), hipMemcpyDeviceToHost, s->stream), "vec D2H");
       }
       if (det_out)
@@ -1132,6 +1141,550 @@ int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, si
       if (vec_out) std::memcpy(vec_out + off * len, s->h_vec.p, k * len * sizeof(double));
     }
   });
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// storm_sweep: several systems per launch.
+//
+// The reference's batch inputs sweep ~10^3 rotation rates x 8 (ell, m) systems with scans of only 100-300 frequencies
+// each (scripts/generate-batch-input-deformed.py:19-35; every `scan` line builds one solver and calls
+// ErasedSolver::scan_and_optimize, src/main.rs:815-831).  One such scan is latency-bound on the GPU (a handful of
+// waves, ~10 dependent refinement rounds, one wave per eigenvector), so the set runs S systems in lock-step: one
+// discriminant launch over every (system, frequency) pair, the bracket refinement rounds of all systems merged, and one
+// eigenvector launch over every mode of every system.  Each (system, frequency) evaluation runs exactly the code a
+// single-system handle runs, so results are bit-identical to S separate handles.
+// =====================================================================================================================
+struct storm_sweep {
+  int device = 0, scheme = 0;
+  size_t n_sys = 0, n_int = 0, p = 0;
+  // Kernels are compiled per (ell == 0, uniform rotation) class, so systems are grouped by class internally:
+  // internal position k holds the caller's system order[k]; class c = positions [cls_begin[c], cls_begin[c+1]).
+  std::vector<size_t> order;
+  size_t cls_begin[4] = {0, 0, 0, 0};
+  std::vector<SystemDev> h_table;          // internal order
+  std::vector<uint64_t> ell;               // caller order
+  std::vector<int64_t> m;
+  DevBuf<double> tab;                      // planes of all systems, internal order
+  DevBuf<SystemDev> d_table;
+  hipStream_t stream = nullptr;
+  hipEvent_t sync_marker = nullptr;
+  DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
+  DevBuf<int> d_sys, d_swaps, d_flags;
+  DevBuf<double> d_terms, d_scale, d_fields, d_nodes;  // post-processing scratch (storm_sweep_modes)
+  DevBuf<long long> d_ids;
+  PinnedBuf h_in, h_out, h_flags;
+  int arith = 0, hex_lanes = 0;
+  size_t steps_bytes_max = size_t(4) << 30;
+  storm_stats stats{};
+  std::mutex mu;
+};
+
+namespace {
+
+constexpr int kSetClasses = 3;  // 0: ell == 0, 1: ell != 0 with bitwise-uniform m*rot, 2: general
+constexpr size_t kSetPad = 4;   // det_hex: an aligned group of 4 frequencies (one wave at 16 lanes each) is one system's
+
+inline bool set_class_ell0(int c) { return c == 0; }
+inline bool set_class_uniform(int c) { return c != 2; }
+
+void set_check_flags(storm_sweep* q) {
+  q->h_flags.reserve(1);
+  int* flags_ptr = reinterpret_cast<int*>(q->h_flags.p);
+  hip_check(hipMemcpyAsync(flags_ptr, q->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, q->stream), "flags D2H");
+  sync_stream(q->stream, q->sync_marker);
+  if (*flags_ptr & 1) {
+    hip_check(hipMemsetAsync(q->d_flags.p, 0, sizeof(int), q->stream), "flags reset");
+    fail(STORM_ERR_SINGULAR, "singular collocation stage matrix (the reference would panic in try_inverse().unwrap())");
+  }
+}
+
+LaunchArgs set_args(storm_sweep* q, int cls, size_t first, size_t n, double* out) {
+  LaunchArgs a;
+  a.sys = q->h_table[q->cls_begin[cls]];
+  a.freq = q->d_freq.p + first; a.n = n; a.out = out; a.flags = q->d_flags.p;
+  a.ell0 = set_class_ell0(cls); a.uniform = set_class_uniform(cls); a.hex_lanes = q->hex_lanes; a.stream = q->stream;
+  a.table = q->d_table.p; a.sys_index = q->d_sys.p + first;
+  return a;
+}
+
+// Discriminants of one frequency list per system.  x[k], cnt[k], f[k] belong to INTERNAL position k.
+void set_det(storm_sweep* q, const std::vector<const double*>& x, const std::vector<size_t>& cnt,
+             const std::vector<double*>& f) {
+  const size_t S = q->n_sys;
+  std::vector<size_t> poff(S + 1, 0);
+  for (size_t k = 0; k < S; ++k) poff[k + 1] = poff[k] + (cnt[k] + kSetPad - 1) / kSetPad * kSetPad;
+  const size_t total = poff[S];
+  if (total == 0) return;
+  if (total > (size_t(1) << 31)) fail(STORM_ERR_INVALID_ARGUMENT, "too many frequencies in one call");
+  q->h_in.reserve(total + (total + 1) / 2);
+  q->h_out.reserve(total);
+  double* hx = q->h_in.p;
+  int* hs = reinterpret_cast<int*>(q->h_in.p + total);
+  for (size_t k = 0; k < S; ++k) {
+    if (!cnt[k]) continue;
+    std::memcpy(hx + poff[k], x[k], cnt[k] * sizeof(double));
+    for (size_t i = poff[k] + cnt[k]; i < poff[k + 1]; ++i) hx[i] = x[k][cnt[k] - 1];  // padding repeats the last one
+    for (size_t i = poff[k]; i < poff[k + 1]; ++i) hs[i] = int(k);
+  }
+  q->d_freq.reserve(total, q->stream); q->d_det.reserve(total, q->stream); q->d_sys.reserve(total, q->stream);
+  hip_check(hipMemcpyAsync(q->d_freq.p, hx, total * sizeof(double), hipMemcpyHostToDevice, q->stream), "freq H2D");
+  hip_check(hipMemcpyAsync(q->d_sys.p, hs, total * sizeof(int), hipMemcpyHostToDevice, q->stream), "system index H2D");
+  for (int c = 0; c < kSetClasses; ++c) {
+    const size_t first = poff[q->cls_begin[c]], n = poff[q->cls_begin[c + 1]] - first;
+    if (!n) continue;
+    hip_check(g_launch_hex[q->arith][q->scheme](set_args(q, c, first, n, q->d_det.p + first)), "det_hex launch");
+    q->stats.launches += 1;
+  }
+  hip_check(hipMemcpyAsync(q->h_out.p, q->d_det.p, total * sizeof(double), hipMemcpyDeviceToHost, q->stream), "det D2H");
+  set_check_flags(q);  // synchronises
+  for (size_t k = 0; k < S; ++k) {
+    if (cnt[k]) std::memcpy(f[k], q->h_out.p + poff[k], cnt[k] * sizeof(double));
+    q->stats.det_evals += cnt[k];
+  }
+}
+
+struct SetBracket : BracketState { size_t pos = 0; };  // pos: internal position of the system
+
+// refine_all over the brackets of every system (sorted by system position): one merged evaluation per round.
+void set_refine(storm_sweep* q, std::vector<SetBracket>& br, uint64_t ulp) {
+  if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
+  if (!(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
+  const size_t S = q->n_sys;
+  std::vector<double> xs, fs;
+  std::vector<size_t> who, cnt(S);
+  std::vector<const double*> xp(S);
+  std::vector<double*> fp(S);
+  for (;;) {
+    xs.clear(); who.clear();
+    std::fill(cnt.begin(), cnt.end(), size_t(0));
+    for (size_t k = 0; k < br.size(); ++k) {
+      SetBracket& b = br[k];
+      if (b.done) continue;
+      double x;
+      if (!b.has_prev) {
+        x = secant(b.lower, b.upper);
+      } else {
+        x = inverse_quadratic(b.lower, b.upper, b.previous);
+        if (x <= b.lower.x || x >= b.upper.x) x = secant(b.lower, b.upper);
+      }
+      if (clamp_proposal(b.upper.x, b.lower.x, x, ulp)) {
+        b.done = true; b.root = x;
+        continue;
+      }
+      b.pending = x;
+      xs.push_back(x); who.push_back(k);
+      cnt[b.pos] += 1;
+    }
+    if (xs.empty()) break;
+    fs.resize(xs.size());
+    size_t at = 0;
+    for (size_t k = 0; k < S; ++k) { xp[k] = xs.data() + at; fp[k] = fs.data() + at; at += cnt[k]; }
+    set_det(q, xp, cnt, fp);
+    q->stats.refine_evals += xs.size();
+    q->stats.refine_rounds += 1;
+    for (size_t i = 0; i < who.size(); ++i) {
+      SetBracket& b = br[who[i]];
+      const Pt next{xs[i], fs[i]};
+      if (!std::isfinite(next.x) || !std::isfinite(next.f))
+        fail(STORM_ERR_NON_FINITE, "non-finite discriminant during bracket refinement");
+      b.evals += 1;
+      if (sign_of(b.upper.f) == sign_of(next.f)) { b.previous = b.upper; b.upper = next; }
+      else { b.previous = b.lower; b.lower = next; }
+      b.has_prev = true;
+    }
+  }
+}
+
+size_t set_eigen_reserve(storm_sweep* q, size_t n) {
+  const size_t n_int = q->n_int, len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+  const size_t per_mode = (n_int * 16 + ustride + len) * sizeof(double);
+  size_t chunk = q->steps_bytes_max / per_mode;
+  if (chunk == 0) chunk = 1;
+  if (chunk > n) chunk = n;
+  if (chunk > 65535) chunk = 65535;  // grid.y of build_steps
+  q->d_freq.reserve(chunk, q->stream); q->d_det.reserve(chunk, q->stream); q->d_sys.reserve(chunk, q->stream);
+  q->d_steps.reserve(chunk * n_int * 16 + 16, q->stream);
+  q->d_upper.reserve(chunk * ustride, q->stream);
+  q->d_vec.reserve(chunk * len, q->stream);
+  q->d_swaps.reserve(chunk * 2, q->stream);
+  return chunk;
+}
+
+// Modes of one chunk, sorted by internal system position: step matrices + elimination + back-substitution, one
+// launch of each per class; eigenvectors and discriminants stay in q->d_vec / q->d_det.
+void set_eigen_chunk(storm_sweep* q, const double* freq, const int* pos, size_t m) {
+  q->h_in.reserve(m + (m + 1) / 2);
+  std::memcpy(q->h_in.p, freq, m * sizeof(double));
+  int* hs = reinterpret_cast<int*>(q->h_in.p + m);
+  std::memcpy(hs, pos, m * sizeof(int));
+  hip_check(hipMemcpyAsync(q->d_freq.p, q->h_in.p, m * sizeof(double), hipMemcpyHostToDevice, q->stream), "freq H2D");
+  hip_check(hipMemcpyAsync(q->d_sys.p, hs, m * sizeof(int), hipMemcpyHostToDevice, q->stream), "system index H2D");
+  const size_t n_int = q->n_int, len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+  size_t first = 0;
+  for (int c = 0; c < kSetClasses; ++c) {
+    size_t last = first;
+    while (last < m && size_t(pos[last]) < q->cls_begin[c + 1]) ++last;
+    const size_t n = last - first;
+    if (n) {
+      double* steps = q->d_steps.p + first * n_int * 16;
+      hip_check(g_launch_build[q->arith][q->scheme](set_args(q, c, first, n, steps)), "build_steps launch");
+      hip_check((q->arith ? storm_fast::launch_eigen : storm::launch_eigen)(
+                    q->h_table[q->cls_begin[c]], set_class_ell0(c), q->d_freq.p + first, n, steps, q->d_upper.p + first * ustride,
+                    q->d_swaps.p + first * 2, q->d_det.p + first, q->d_vec.p + first * len, q->stream, q->d_table.p,
+                    q->d_sys.p + first),
+                "eigen launch");
+      q->stats.launches += 3;
+    }
+    first = last;
+  }
+  q->stats.eigenvectors += m;
+}
+
+// Caller-order mode lists -> internal order.  src[j] = index (in the caller's concatenated arrays) of internal mode j.
+void set_mode_order(const storm_sweep* q, const size_t* offsets, std::vector<size_t>& src, std::vector<int>& pos) {
+  src.clear(); pos.clear();
+  for (size_t k = 0; k < q->n_sys; ++k) {
+    const size_t u = q->order[k];
+    if (offsets[u + 1] < offsets[u]) fail(STORM_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    for (size_t i = offsets[u]; i < offsets[u + 1]; ++i) { src.push_back(i); pos.push_back(int(k)); }
+  }
+}
+
+void set_validate_offsets(const storm_sweep* q, const size_t* offsets) {
+  if (!offsets) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+  if (offsets[0] != 0) fail(STORM_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  for (size_t u = 0; u < q->n_sys; ++u)
+    if (offsets[u + 1] < offsets[u]) fail(STORM_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+}
+
+}  // namespace
+
+extern "C" {
+
+int storm_sweep_create(const storm_system_desc* descs, size_t n_sys, storm_sweep** out) {
+  if (out) *out = nullptr;
+  storm_sweep* q = nullptr;
+  int rc = guarded([&] {
+    if (!out || (n_sys && !descs)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_sys == 0) fail(STORM_ERR_INVALID_ARGUMENT, "a sweep needs at least one system");
+    if (n_sys > (size_t(1) << 24)) fail(STORM_ERR_INVALID_ARGUMENT, "too many systems");
+    const storm_system_desc& d0 = descs[0];
+    if (d0.scheme < 0 || d0.scheme >= kNumSchemes) fail(STORM_ERR_INVALID_ARGUMENT, "unknown difference scheme");
+    if (d0.p != size_t(scheme_points(d0.scheme)))
+      fail(STORM_ERR_INVALID_ARGUMENT, "p does not match the number of collocation points of the scheme");
+    if (d0.n_int > (size_t(1) << 40)) fail(STORM_ERR_INVALID_ARGUMENT, "n_int too large");
+    for (size_t u = 0; u < n_sys; ++u) {
+      const storm_system_desc& d = descs[u];
+      if (d.scheme != d0.scheme || d.n_int != d0.n_int || d.p != d0.p)
+        fail(STORM_ERR_INVALID_ARGUMENT, "all systems of a sweep must share the scheme and the number of grid intervals");
+      if (d.n_int && (!d.u || !d.v_gamma || !d.a_star || !d.c1 || !d.rot || !d.delta_over_x))
+        fail(STORM_ERR_INVALID_ARGUMENT, "null coefficient array");
+    }
+    int ndev = 0;
+    hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    if (ndev <= 0) fail(STORM_ERR_HIP, "no HIP device available");
+    q = new storm_sweep();
+    hip_check(hipGetDevice(&q->device), "hipGetDevice");
+    q->scheme = d0.scheme; q->n_sys = n_sys; q->n_int = d0.n_int; q->p = d0.p;
+    const size_t elems = planes_elems(q->n_int, q->p);
+    // planes of every system, built straight into the pinned block the upload is staged from (caller order first:
+    // the class of a system is only known once its planes are)
+    q->h_in.reserve(elems * n_sys);
+    std::vector<char> uniform(n_sys, 1);
+    std::vector<double> rotm0(n_sys, 0.0);
+    {
+      const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+      const size_t n_thr = std::min<size_t>({n_sys, hw, size_t(16)});
+      std::atomic<size_t> next{0};
+      auto work = [&] {
+        for (size_t u; (u = next.fetch_add(1)) < n_sys;) {
+          bool uni = true;
+          build_planes(descs[u], q->h_in.p + u * elems, uni, rotm0[u]);
+          uniform[u] = uni ? 1 : 0;
+        }
+      };
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+    }
+    std::vector<int> cls(n_sys);
+    for (size_t u = 0; u < n_sys; ++u) cls[u] = descs[u].ell == 0 ? 0 : (uniform[u] ? 1 : 2);
+    for (int c = 0; c < kSetClasses; ++c) {
+      q->cls_begin[c] = q->order.size();
+      for (size_t u = 0; u < n_sys; ++u) if (cls[u] == c) q->order.push_back(u);
+    }
+    q->cls_begin[kSetClasses] = n_sys;
+    q->stream = MemoryCache::get().take_stream(q->device);
+    q->tab.reserve(elems * n_sys, nullptr);
+    q->d_table.reserve(n_sys, nullptr);
+    q->h_table.resize(n_sys);
+    q->ell.resize(n_sys); q->m.resize(n_sys);
+    for (size_t k = 0; k < n_sys; ++k) {
+      const size_t u = q->order[k];
+      const storm_system_desc& d = descs[u];
+      hip_check(hipMemcpyAsync(q->tab.p + k * elems, q->h_in.p + u * elems, elems * sizeof(double), hipMemcpyHostToDevice,
+                               q->stream), "planes H2D");
+      SystemDev& sd = q->h_table[k];
+      const double ell = double(d.ell);
+      sd.tab = q->tab.p + k * elems;
+      sd.stride = padded_stride(d.n_int);
+      sd.plane = sd.stride * d.p;
+      sd.n_int = d.n_int;
+      sd.ell = ell;
+      sd.lambda = ell * (ell + 1.0);
+      sd.inner_c1 = d.inner_c1;
+      sd.inner_rotm = double(d.m) * d.inner_rot;
+      sd.outer_u = d.outer_u;
+      sd.rotm_uniform = rotm0[u];
+      q->ell[u] = d.ell; q->m[u] = d.m;
+    }
+    // the table is copied from pageable memory: hipMemcpyAsync stages it before returning
+    hip_check(hipMemcpyAsync(q->d_table.p, q->h_table.data(), n_sys * sizeof(SystemDev), hipMemcpyHostToDevice, q->stream),
+              "system table H2D");
+    q->d_flags.reserve(1);
+    hip_check(hipMemsetAsync(q->d_flags.p, 0, sizeof(int), q->stream), "flags memset");
+    sync_stream(q->stream, q->sync_marker);  // h_in is reused by the first evaluation
+    *out = q;
+  });
+  if (rc != STORM_OK && q) {
+    storm_sweep_destroy(q);
+    if (out) *out = nullptr;
+  }
+  return rc;
+}
+
+void storm_sweep_destroy(storm_sweep* q) {
+  if (!q) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(q->device);
+  if (q->stream) { (void)hipStreamSynchronize(q->stream); MemoryCache::get().give_stream(q->device, q->stream); }
+  if (q->sync_marker) (void)hipEventDestroy(q->sync_marker);
+  q->tab.release(); q->d_table.release(); q->d_freq.release(); q->d_det.release(); q->d_steps.release(); q->d_upper.release();
+  q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
+  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
+  (void)hipSetDevice(prev);
+  delete q;
+}
+
+size_t storm_sweep_size(const storm_sweep* q) { return q ? q->n_sys : 0; }
+size_t storm_sweep_n_int(const storm_sweep* q) { return q ? q->n_int : 0; }
+
+int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
+  return guarded([&] {
+    if (!q || !key) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    const std::string k(key);
+    if (k == "arithmetic") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "arithmetic must be 0 (parity) or 1 (fast)");
+      q->arith = int(value);
+    } else if (k == "hex_lanes") {
+      if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
+      q->hex_lanes = int(value);
+    } else if (k == "steps_bytes_max") {
+      if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
+      q->steps_bytes_max = size_t(value);
+    } else {
+      fail(STORM_ERR_INVALID_ARGUMENT, "unknown option: " + k);
+    }
+  });
+}
+
+int storm_sweep_stats(storm_sweep* q, storm_stats* out, int reset) {
+  return guarded([&] {
+    if (!q || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    *out = q->stats;
+    if (reset) q->stats = storm_stats{};
+  });
+}
+
+int storm_sweep_det(storm_sweep* q, const size_t* offsets, const double* freq, double* det_out) {
+  return guarded([&] {
+    if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    set_validate_offsets(q, offsets);
+    if (offsets[q->n_sys] && (!freq || !det_out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    DeviceGuard g(q->device);
+    const size_t S = q->n_sys;
+    std::vector<const double*> x(S);
+    std::vector<double*> f(S);
+    std::vector<size_t> cnt(S);
+    for (size_t k = 0; k < S; ++k) {
+      const size_t u = q->order[k];
+      x[k] = freq + offsets[u]; f[k] = det_out + offsets[u]; cnt[k] = offsets[u + 1] - offsets[u];
+    }
+    set_det(q, x, cnt, f);
+  });
+}
+
+int storm_sweep_scan_and_optimize(storm_sweep* q, const size_t* freq_offsets, const double* freq, uint64_t ulp,
+                                       storm_bracket* out, size_t cap, size_t* out_offsets, int* had_invalid, double* det_out,
+                                       uint64_t* index_out) {
+  return guarded([&] {
+    if (!q || !out_offsets || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    set_validate_offsets(q, freq_offsets);
+    const size_t S = q->n_sys, total = freq_offsets[S];
+    for (size_t u = 0; u <= S; ++u) out_offsets[u] = 0;
+    if (had_invalid) for (size_t u = 0; u < S; ++u) had_invalid[u] = 0;
+    if (total && !freq) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    DeviceGuard g(q->device);
+    std::vector<double> local;
+    double* dets = det_out;
+    if (!dets) { local.resize(total); dets = local.data(); }
+    std::vector<const double*> x(S);
+    std::vector<double*> f(S);
+    std::vector<size_t> cnt(S);
+    for (size_t k = 0; k < S; ++k) {
+      const size_t u = q->order[k];
+      x[k] = freq + freq_offsets[u]; f[k] = dets + freq_offsets[u]; cnt[k] = freq_offsets[u + 1] - freq_offsets[u];
+    }
+    set_det(q, x, cnt, f);
+    // FilterSignSwap + finite filter per system (src/bracket.rs:236-250, src/dynamic_interface.rs:128-138), gathered in
+    // internal order (what the merged refinement rounds need); idx = grid index inside the system's own scan
+    std::vector<SetBracket> br;
+    std::vector<uint64_t> idx;
+    std::vector<size_t> n_br(S, 0);  // by caller index
+    for (size_t k = 0; k < S; ++k) {
+      const size_t u = q->order[k];
+      const double* xs = x[k];
+      const double* fs = f[k];
+      bool invalid = false;
+      for (size_t i = 0; i + 1 < cnt[k]; ++i) {
+        const double a = fs[i], b = fs[i + 1];
+        if (sign_of(a) != sign_of(b)) {
+          if (std::isfinite(a) && std::isfinite(b)) {
+            if (!std::isfinite(xs[i]) || !std::isfinite(xs[i + 1])) fail(STORM_ERR_BRACKET, "non-finite scan frequency");
+            SetBracket st;
+            st.lower = Pt{xs[i], a};
+            st.upper = Pt{xs[i + 1], b};
+            st.pos = k;
+            br.push_back(st);
+            idx.push_back(i);
+            n_br[u] += 1;
+          } else {
+            invalid = true;
+          }
+        }
+      }
+      if (had_invalid) had_invalid[u] = invalid ? 1 : 0;
+    }
+    for (size_t u = 0; u < S; ++u) out_offsets[u + 1] = out_offsets[u] + n_br[u];
+    if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+    set_refine(q, br, ulp);
+    std::vector<size_t> at(out_offsets, out_offsets + S);
+    for (size_t j = 0; j < br.size(); ++j) {
+      const size_t u = q->order[br[j].pos], dst = at[u]++;
+      out[dst] = storm_bracket{br[j].lower.x, br[j].lower.f, br[j].upper.x, br[j].upper.f, br[j].root, br[j].evals};
+      if (index_out) index_out[dst] = idx[j];
+    }
+  });
+}
+
+int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t* offsets, const double* freq,
+                                 double* det_out, double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out,
+                                 size_t node_cap) {
+  return guarded([&] {
+    if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    set_validate_offsets(q, offsets);
+    const size_t S = q->n_sys, n = offsets[S];
+    if (n == 0) return;
+    if (!freq) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    const bool post = posts != nullptr;
+    if (post && !ids_out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (!post && (fields_out || ids_out || nodes_out))
+      fail(STORM_ERR_INVALID_ARGUMENT, "fields, ids and nodes need the post-processing handles");
+    if (!post && !vec_out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t np = q->n_int + 1, len = np * 4;
+    if (post)
+      for (size_t u = 0; u < S; ++u) {
+        if (offsets[u + 1] == offsets[u]) continue;
+        if (!posts[u]) fail(STORM_ERR_INVALID_ARGUMENT, "null post-processing handle");
+        if (posts[u]->model.n_pts != np)
+          fail(STORM_ERR_INVALID_ARGUMENT, "the solver grid is not the post-processing model's grid (n_int + 1 != n_pts)");
+        if (posts[u]->device != q->device) fail(STORM_ERR_INVALID_ARGUMENT, "sweep and post-processing handle live on different devices");
+      }
+    std::lock_guard<std::mutex> lock(q->mu);
+    DeviceGuard g(q->device);
+    std::vector<size_t> src;
+    std::vector<int> pos;
+    set_mode_order(q, offsets, src, pos);
+    std::vector<double> fr(n);
+    for (size_t j = 0; j < n; ++j) fr[j] = freq[src[j]];
+    const bool want_fields = fields_out != nullptr;
+    const size_t ncap = nodes_out ? node_cap : 0;
+    size_t chunk = set_eigen_reserve(q, n);
+    if (post) {
+      const size_t per_mode = (np * (1 + (want_fields ? kPostFields : 0)) + ncap + 8) * sizeof(double);
+      chunk = std::min(chunk, std::max<size_t>(1, q->steps_bytes_max / per_mode));
+      q->d_terms.reserve(chunk * np, q->stream);
+      q->d_scale.reserve(chunk, q->stream);
+      q->d_ids.reserve(chunk * 4, q->stream);
+      if (want_fields) q->d_fields.reserve(chunk * kPostFields * np, q->stream);
+      if (ncap) q->d_nodes.reserve(chunk * ncap, q->stream);
+    }
+    std::vector<long long> h_ids;
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t k = std::min(chunk, n - off);
+      set_eigen_chunk(q, fr.data() + off, pos.data() + off, k);
+      if (post) {
+        // one (ell, m, model) per system: its modes are a contiguous run of the chunk
+        for (size_t a = 0; a < k;) {
+          size_t b = a;
+          while (b < k && pos[off + b] == pos[off + a]) ++b;
+          const size_t u = q->order[size_t(pos[off + a])];
+          storm_postproc* pp = posts[u];
+          {
+            std::lock_guard<std::mutex> lock_p(pp->mu);
+            ensure_model(pp, q->stream);
+          }
+          PostArgs pa;
+          pa.model = pp->model; pa.par = post_params(q->ell[u], q->m[u]);
+          pa.freq = q->d_freq.p + a; pa.vec = q->d_vec.p + a * len; pa.n = b - a;
+          pa.terms = q->d_terms.p + a * np; pa.scale = q->d_scale.p + a;
+          pa.fields = want_fields ? q->d_fields.p + a * kPostFields * np : nullptr;
+          pa.ids = q->d_ids.p + a * 4;
+          pa.nodes = ncap ? q->d_nodes.p + a * ncap : nullptr;
+          pa.node_cap = ncap; pa.stream = q->stream;
+          hip_check(launch_postprocess(pa), "postprocess launch");
+          q->stats.launches += want_fields ? 3 : 2;
+          a = b;
+        }
+      }
+      // results to the host: staged in pinned memory in internal order, scattered to the caller's order
+      const size_t nv = vec_out ? k * len : 0, nf = want_fields ? k * kPostFields * np : 0, nn = ncap ? k * ncap : 0;
+      q->h_out.reserve(nv + nf + nn + k + 1);
+      double* hv = q->h_out.p; double* hf = hv + nv; double* hn = hf + nf; double* hd = hn + nn;
+      if (nv) hip_check(hipMemcpyAsync(hv, q->d_vec.p, nv * sizeof(double), hipMemcpyDeviceToHost, q->stream), "vec D2H");
+      if (nf) hip_check(hipMemcpyAsync(hf, q->d_fields.p, nf * sizeof(double), hipMemcpyDeviceToHost, q->stream), "fields D2H");
+      if (nn) hip_check(hipMemcpyAsync(hn, q->d_nodes.p, nn * sizeof(double), hipMemcpyDeviceToHost, q->stream), "nodes D2H");
+      hip_check(hipMemcpyAsync(hd, q->d_det.p, k * sizeof(double), hipMemcpyDeviceToHost, q->stream), "det D2H");
+      if (post) {
+        h_ids.resize(k * 4);
+        hip_check(hipMemcpyAsync(h_ids.data(), q->d_ids.p, k * 4 * sizeof(long long), hipMemcpyDeviceToHost, q->stream), "ids D2H");
+      }
+      set_check_flags(q);  // synchronises
+      for (size_t j = 0; j < k; ++j) {
+        const size_t dst = src[off + j];
+        if (vec_out) std::memcpy(vec_out + dst * len, hv + j * len, len * sizeof(double));
+        if (want_fields) std::memcpy(fields_out + dst * kPostFields * np, hf + j * kPostFields * np, kPostFields * np * sizeof(double));
+        if (ncap) std::memcpy(nodes_out + dst * ncap, hn + j * ncap, ncap * sizeof(double));
+        if (det_out) det_out[dst] = hd[j];
+        if (post)
+          ids_out[dst] = storm_mode_id{uint64_t(h_ids[j * 4]), uint64_t(h_ids[j * 4 + 1]), int64_t(h_ids[j * 4 + 2]),
+                                       uint64_t(h_ids[j * 4 + 3])};
+      }
+    }
+  });
+}
+
+int storm_sweep_eigenvectors(storm_sweep* q, const size_t* offsets, const double* freq, double* det_out,
+                                       double* vec_out) {
+  return storm_sweep_modes(q, nullptr, offsets, freq, det_out, vec_out, nullptr, nullptr, nullptr, 0);
 }
 
 }  // extern "C"

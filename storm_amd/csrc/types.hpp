@@ -49,6 +49,12 @@ struct LaunchArgs {
   bool ell0, uniform;
   int hex_lanes;       // det_hex only: lanes per frequency, 16 or 32; 0 = pick by wave-slot packing
   hipStream_t stream;
+  // Several systems in one launch (storm_sweep): frequency i belongs to system
+  // table[sys_index[i]] (device arrays).  All systems of a launch share n_int, the scheme and the (ell0, uniform)
+  // class; det_hex additionally needs every aligned group of 4 frequencies to belong to one system (the host pads).
+  // table == nullptr: the one system `sys`.
+  const SystemDev* table = nullptr;
+  const int* sys_index = nullptr;
 };
 typedef hipError_t (*launch_fn)(const LaunchArgs&);
 

@@ -61,7 +61,10 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
            "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postprocess_batch",
            "storm_modes_batch", "storm_coupling_matrices", "storm_postproc_last_kernel_ms",
-           "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats"]
+           "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats",
+           "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
+           "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
+           "storm_sweep_set_option"]
 
 _lib = None
 
@@ -107,6 +110,22 @@ def load_library():
     L.storm_memory_cache_stats.restype = None
     L.storm_postproc_last_kernel_ms.restype = C.c_double
     L.storm_postproc_last_kernel_ms.argtypes = [C.c_void_p]
+    _sp = C.POINTER(C.c_size_t)
+    L.storm_sweep_create.argtypes = [C.POINTER(SystemDesc), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.storm_sweep_destroy.argtypes = [C.c_void_p]
+    L.storm_sweep_destroy.restype = None
+    L.storm_sweep_size.restype = C.c_size_t
+    L.storm_sweep_size.argtypes = [C.c_void_p]
+    L.storm_sweep_n_int.restype = C.c_size_t
+    L.storm_sweep_n_int.argtypes = [C.c_void_p]
+    L.storm_sweep_det.argtypes = [C.c_void_p, _sp, _dp, _dp]
+    L.storm_sweep_scan_and_optimize.argtypes = [C.c_void_p, _sp, _dp, C.c_uint64, C.POINTER(Bracket), C.c_size_t, _sp,
+                                                C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
+    L.storm_sweep_eigenvectors.argtypes = [C.c_void_p, _sp, _dp, _dp, _dp]
+    L.storm_sweep_modes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _sp, _dp, _dp, _dp, _dp, C.POINTER(ModeId), _dp,
+                                    C.c_size_t]
+    L.storm_sweep_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L.storm_sweep_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L
     return L
 
@@ -243,6 +262,122 @@ class HipSolver:
         out["det"] = dets
         out["vec"] = vec
         return out
+
+
+def _offsets(lists):
+    off = np.zeros(len(lists) + 1, dtype=np.uintp)
+    np.cumsum([len(x) for x in lists], out=off[1:])
+    return off
+
+
+def _sp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_size_t))
+
+
+class HipSweep:
+    """One storm_sweep handle: S systems (same scheme and grid; ell, m and coefficients free) evaluated in lock-step.
+    `systems` is a list of (ell, m, system dict) with the dicts HipSolver takes.  Per-system inputs and outputs are
+    Python lists with one entry per system."""
+
+    def __init__(self, scheme, systems, n_int, p):
+        L = load_library()
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        keys = ("u", "v_gamma", "a_star", "c1", "rot", "delta_over_x")
+        descs = (SystemDesc * max(len(systems), 1))()
+        keep = []
+        for k, (ell, m, system) in enumerate(systems):
+            arrs = {q: _f64(system[q]) for q in keys}
+            for q, a in arrs.items():
+                if a.size != n_int * p:
+                    raise ValueError(f"system {k}, {q}: expected {n_int * p} entries, got {a.size}")
+            keep.append(arrs)
+            descs[k] = SystemDesc(scheme, ell, m, n_int, p, *[_p(arrs[q]) for q in keys], float(system["inner_c1"]),
+                                  float(system["inner_rot"]), float(system["outer_u"]))
+        h = C.c_void_p()
+        _check(L.storm_sweep_create(descs, len(systems), C.byref(h)))
+        self._h = h
+        self.n_sys, self.n_int, self.p, self.scheme = len(systems), n_int, p, scheme
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().storm_sweep_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _check(load_library().storm_sweep_set_option(self._h, key.encode(), int(value)))
+
+    def stats(self, reset=False):
+        s = Stats()
+        _check(load_library().storm_sweep_stats(self._h, C.byref(s), 1 if reset else 0))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def _flat(self, lists):
+        if len(lists) != self.n_sys:
+            raise ValueError(f"expected {self.n_sys} per-system lists, got {len(lists)}")
+        lists = [_f64(np.atleast_1d(x)).ravel() for x in lists]
+        off = _offsets(lists)
+        flat = np.concatenate(lists) if lists else np.empty(0)
+        return off, _f64(flat)
+
+    def det(self, freq_lists):
+        off, f = self._flat(freq_lists)
+        out = np.empty(f.size)
+        _check(load_library().storm_sweep_det(self._h, _sp(off), _p(f), _p(out)))
+        return [out[off[u]:off[u + 1]] for u in range(self.n_sys)]
+
+    def scan_and_optimize(self, freq_lists, ulp):
+        """-> per system (brackets, dets, had_invalid), exactly what HipSolver.scan_and_optimize returns."""
+        L = load_library()
+        off, f = self._flat(freq_lists)
+        cap = max(1, f.size)
+        out = (Bracket * cap)()
+        idx = (C.c_uint64 * cap)()
+        dets = np.empty(f.size)
+        ooff = np.zeros(self.n_sys + 1, dtype=np.uintp)
+        inv = (C.c_int * max(self.n_sys, 1))()
+        _check(L.storm_sweep_scan_and_optimize(self._h, _sp(off), _p(f), ulp, out, cap, _sp(ooff), inv, _p(dets), idx))
+        res = []
+        for u in range(self.n_sys):
+            br = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
+                       index=int(idx[i])) for i, b in zip(range(int(ooff[u]), int(ooff[u + 1])), out[int(ooff[u]):int(ooff[u + 1])])]
+            res.append((br, dets[off[u]:off[u + 1]], bool(inv[u])))
+        return res
+
+    def eigenvector(self, freq_lists):
+        off, f = self._flat(freq_lists)
+        dets = np.empty(f.size)
+        vec = np.empty((f.size, (self.n_int + 1) * 4))
+        _check(load_library().storm_sweep_eigenvectors(self._h, _sp(off), _p(f), _p(dets), _p(vec)))
+        return [(dets[off[u]:off[u + 1]], vec[off[u]:off[u + 1]]) for u in range(self.n_sys)]
+
+    def modes(self, posts, freq_lists, want_vec=False, want_fields=True, node_cap=None):
+        """storm_sweep_modes; posts: one HipPostproc per system (may repeat).  -> per system the dict HipSolver.modes returns."""
+        off, f = self._flat(freq_lists)
+        npts = self.n_int + 1
+        cap = npts if node_cap is None else node_cap
+        n = f.size
+        dets = np.empty(n)
+        vec = np.empty((n, npts * 4)) if want_vec else None
+        fields = np.empty((n, len(POST_FIELDS), npts)) if want_fields else None
+        ids = (ModeId * max(n, 1))()
+        nodes = np.full((n, max(cap, 1)), np.nan)
+        hs = (C.c_void_p * max(self.n_sys, 1))(*[q._h for q in posts])
+        _check(load_library().storm_sweep_modes(self._h, hs, _sp(off), _p(f), _p(dets), _p(vec) if want_vec else None,
+                                                _p(fields) if want_fields else None, ids, _p(nodes) if cap else None, cap))
+        allr = _post_result(n, fields, ids, nodes, cap)
+        res = []
+        for u in range(self.n_sys):
+            a, b = int(off[u]), int(off[u + 1])
+            res.append(dict(fields=fields[a:b] if want_fields else None, ids=allr["ids"][a:b], n_nodes=allr["n_nodes"][a:b],
+                            nodes=allr["nodes"][a:b], det=dets[a:b], vec=vec[a:b] if want_vec else None))
+        return res
 
 
 def _post_result(n, fields, ids, nodes, cap):

@@ -73,6 +73,19 @@ def load_host_library():
     L.storm_host_coupling_matrices.argtypes = [C.c_void_p, C.c_size_t, _u64p, _dp, _dp, C.c_int64, C.POINTER(_dp), _dp]
     L.storm_host_modes.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, C.c_int, _dp, _i64p, _u64p, _dp, C.c_size_t]
     L.storm_host_rev_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _dp]
+    _sp, _vpp = C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)
+    L.storm_host_sweep_new.restype = C.c_void_p
+    L.storm_host_sweep_new.argtypes = [_vpp, _u64p, _i64p, C.c_size_t, C.c_int, _dp, C.c_size_t]
+    L.storm_host_sweep_free.argtypes = [C.c_void_p]
+    L.storm_host_sweep_len.restype = C.c_size_t
+    L.storm_host_sweep_len.argtypes = [C.c_void_p]
+    L.storm_host_sweep_handle.restype = C.c_void_p
+    L.storm_host_sweep_handle.argtypes = [C.c_void_p]
+    L.storm_host_sweep_det.argtypes = [C.c_void_p, _sp, _dp, _dp]
+    L.storm_host_sweep_scan_and_optimize.argtypes = [C.c_void_p, _sp, _dp, C.c_int, C.c_uint64, C.c_double,
+                                                     C.POINTER(Bracket), C.c_size_t, _sp, C.POINTER(C.c_int)]
+    L.storm_host_sweep_eigenvectors.argtypes = [C.c_void_p, _sp, _dp, _dp]
+    L.storm_host_sweep_modes.argtypes = [C.c_void_p, _vpp, _sp, _dp, C.c_int, _dp, _i64p, _u64p, _dp, C.c_size_t]
     _lib = L
     return L
 
@@ -347,6 +360,119 @@ class PostProcessor:
     def __del__(self):
         try:
             load_host_library().storm_host_postproc_free(self._h)
+        except Exception:
+            pass
+
+
+class SolverSweep:
+    """Many (model, ell, m) systems on one solver grid evaluated in lock-step on the device (storm_sweep): one
+    ErasedSolver per `scan` line of a rotation-sweep batch input (reference src/main.rs:815-831,
+    scripts/generate-batch-input-deformed.py:19-35) as one object.  `systems`: list of (model, ell, m); models may
+    repeat.  Per-system inputs/outputs are lists indexed by system; results are bit-identical to one ErasedSolver each."""
+
+    def __init__(self, systems, scheme, solver_grid):
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        g = _f64(solver_grid)
+        n = len(systems)
+        models = (C.c_void_p * max(n, 1))(*[mdl._h for mdl, _, _ in systems])
+        ells = np.array([e for _, e, _ in systems], dtype=np.uint64)
+        ms = np.array([m for _, _, m in systems], dtype=np.int64)
+        h = load_host_library().storm_host_sweep_new(models, ells.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                     ms.ctypes.data_as(C.POINTER(C.c_int64)), n, scheme, _p(g), g.size)
+        if not h:
+            raise _err()
+        self._h = C.c_void_p(h)
+        self._models = [mdl for mdl, _, _ in systems]
+        self.n_sys, self.scheme = n, scheme
+        self.n_int = load_host_library().storm_host_sweep_len(self._h)
+
+    def raw_handle(self):
+        return load_host_library().storm_host_sweep_handle(self._h)
+
+    def set_option(self, key, value):
+        L = ffi.load_library()
+        rc = L.storm_sweep_set_option(C.c_void_p(self.raw_handle()), key.encode(), int(value))
+        if rc != 0:
+            raise ffi.StormError(rc, L.storm_last_error().decode())
+
+    def stats(self, reset=False):
+        L = ffi.load_library()
+        s = ffi.Stats()
+        rc = L.storm_sweep_stats(C.c_void_p(self.raw_handle()), C.byref(s), 1 if reset else 0)
+        if rc != 0:
+            raise ffi.StormError(rc, L.storm_last_error().decode())
+        return {k: int(getattr(s, k)) for k, _ in ffi.Stats._fields_}
+
+    def _flat(self, lists):
+        if len(lists) != self.n_sys:
+            raise ValueError(f"expected {self.n_sys} per-system lists, got {len(lists)}")
+        lists = [_f64(np.atleast_1d(x)).ravel() for x in lists]
+        off = np.zeros(self.n_sys + 1, dtype=np.uintp)
+        np.cumsum([x.size for x in lists], out=off[1:])
+        return off, _f64(np.concatenate(lists))
+
+    @staticmethod
+    def _sp(a):
+        return a.ctypes.data_as(C.POINTER(C.c_size_t))
+
+    def det(self, freq_lists):
+        off, f = self._flat(freq_lists)
+        out = np.empty(f.size)
+        if load_host_library().storm_host_sweep_det(self._h, self._sp(off), _p(f), _p(out)) != 0:
+            raise _err()
+        return [out[off[u]:off[u + 1]] for u in range(self.n_sys)]
+
+    def scan_and_optimize(self, freq_grids, precision):
+        """-> per system (brackets, had_invalid), as ErasedSolver.scan_and_optimize returns them."""
+        off, f = self._flat(freq_grids)
+        cap = max(1, f.size)
+        out = (Bracket * cap)()
+        ooff = np.zeros(self.n_sys + 1, dtype=np.uintp)
+        inv = (C.c_int * max(self.n_sys, 1))()
+        rc = load_host_library().storm_host_sweep_scan_and_optimize(self._h, self._sp(off), _p(f), precision.kind,
+                                                                    precision.ulp, precision.rel, out, cap,
+                                                                    self._sp(ooff), inv)
+        if rc != 0:
+            raise _err()
+        res = []
+        for u in range(self.n_sys):
+            br = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals))
+                  for b in out[int(ooff[u]):int(ooff[u + 1])]]
+            res.append((br, bool(inv[u])))
+        return res
+
+    def eigenvector(self, root_lists):
+        off, f = self._flat(root_lists)
+        out = np.empty((f.size, (self.n_int + 1) * 4))
+        if load_host_library().storm_host_sweep_eigenvectors(self._h, self._sp(off), _p(f), _p(out)) != 0:
+            raise _err()
+        return [out[off[u]:off[u + 1]] for u in range(self.n_sys)]
+
+    def modes(self, posts, root_lists, want_fields=False):
+        """Eigenvectors + post-processing of every system's modes in one device pass; posts: one PostProcessor per
+        system (may repeat).  -> per system the dict PostProcessor.modes returns."""
+        off, f = self._flat(root_lists)
+        n, npts = f.size, self.n_int + 1
+        fields = np.empty((n, len(POST_FIELDS), npts)) if want_fields else None
+        ids = np.empty((n, 3), dtype=np.int64)
+        nn = np.zeros(n, dtype=np.uint64)
+        nodes = np.full((n, npts), np.nan)
+        hs = (C.c_void_p * max(self.n_sys, 1))(*[q._h if q is not None else None for q in posts])
+        rc = load_host_library().storm_host_sweep_modes(
+            self._h, hs, self._sp(off), _p(f), 1 if want_fields else 0, _p(fields) if want_fields else None,
+            ids.ctypes.data_as(C.POINTER(C.c_int64)), nn.ctypes.data_as(C.POINTER(C.c_uint64)), _p(nodes), npts)
+        if rc != 0:
+            raise _err()
+        res = []
+        for u in range(self.n_sys):
+            a, b = int(off[u]), int(off[u + 1])
+            res.append(PostProcessor._result(fields[a:b] if want_fields else None, ids[a:b], nn[a:b], nodes[a:b]))
+        return res
+
+    def __del__(self):
+        try:
+            load_host_library().storm_host_sweep_free(self._h)
         except Exception:
             pass
 

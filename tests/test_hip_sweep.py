@@ -1,0 +1,234 @@
+"""GPU parity of storm_sweep (several systems per launch) against the CPU oracle run
+system by system, and against one storm_solver handle per system: discriminants, brackets (points, roots,
+evals, grid indices), the invalid-number flags, eigenvectors and post-processing, all bit-exact.  The reference
+has no batched object (each `scan` line builds its own ErasedSolver, src/main.rs:815-831), so the contract is
+"identical to the per-system calls"."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same_bits(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+def same_brackets(ref, got):
+    keys = ("lo_x", "lo_f", "hi_x", "hi_f", "root")
+    if len(ref) != len(got):
+        return False
+    for r, g in zip(ref, got):
+        if any(bits(r[k]) != bits(g[k]) for k in keys) or r["evals"] != g["evals"]:
+            return False
+        if "index" in r and "index" in g and r["index"] != g["index"]:
+            return False
+    return True
+
+
+def rotating(oracle, golden_dir, name, rot):
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, f"gsm_{name}.npz"))
+    if rot is not None:
+        if np.isscalar(rot):
+            model.set_rotation_constant(rot)
+        else:
+            model.set_field("rot", rot(model.field("r_coord")))
+    return model
+
+
+def sweep_from_oracle(solvers):
+    import storm_amd
+    from storm_amd import ffi
+    o0 = solvers[0]
+    return ffi.HipSweep(o0.scheme, [(o.ell, o.m, o.system()) for o in solvers], o0.n_int, o0.p)
+
+
+# (ell, m, rotation): every kernel class (ell = 0, uniform rotation, differential rotation), interleaved so the
+# internal grouping by class has to permute them
+MIXED = [(2, 0, None), (0, 0, 0.1), (1, 1, 0.1), (2, -1, lambda x: 0.05 + 0.1 * np.exp(-3.0 * x)), (0, 0, None),
+         (3, 2, 0.07), (1, -1, lambda x: 0.02 + 0.03 * x), (2, 2, 0.1)]
+
+
+@pytest.mark.parametrize("scheme", ["colloc4", "colloc2", "magnus2", "colloc6", "colloc8", "magnus4", "magnus6", "magnus8"])
+def test_sweep_scan_bit_exact(oracle, golden_dir, scheme):
+    models = [rotating(oracle, golden_dir, "zams", rot) for _, _, rot in MIXED]
+    grid = models[0].field("r_coord")
+    solvers = [oracle.Solver(mdl, ell, m, scheme, grid) for mdl, (ell, m, _) in zip(models, MIXED)]
+    # ragged frequency lists (lengths not multiples of 4, one empty, one single point)
+    grids = [oracle.linspace(1.0 + 0.1 * k, 11.0 + k, 37 + 5 * k) for k in range(len(MIXED))]
+    grids[4] = np.empty(0)
+    grids[6] = np.array([3.25])
+    ulp = oracle.relative_to_ulp(1e-8)
+    sweep = sweep_from_oracle(solvers)
+    dets = sweep.det(grids)
+    got = sweep.scan_and_optimize(grids, ulp)
+    n_modes = 0
+    for k, o in enumerate(solvers):
+        ref, rdets, rinv = o.scan_and_optimize(grids[k], ulp, threads=16)
+        assert same_bits(dets[k], rdets), (scheme, k, "det")
+        br, sdets, inv = got[k]
+        assert same_bits(sdets, rdets), (scheme, k, "scan det")
+        assert inv == rinv, (scheme, k)
+        assert same_brackets(ref, br), (scheme, k, "brackets")
+        n_modes += len(ref)
+    assert n_modes > 10
+    st = sweep.stats()
+    assert st["refine_rounds"] > 0 and st["refine_evals"] == sum(b["evals"] for br, _, _ in got for b in br)
+    if scheme in ("colloc4", "magnus2"):
+        # eigenvectors of every mode of every system in one pass
+        roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+        vecs = sweep.eigenvector(roots)
+        for k, o in enumerate(solvers):
+            if roots[k].size == 0:
+                assert vecs[k][1].shape[0] == 0
+                continue
+            rdet, rvec = o.eigenvector(roots[k], threads=16)
+            assert same_bits(vecs[k][1], rvec), (scheme, k, "eigenvectors")
+            assert same_bits(vecs[k][0], rdet), (scheme, k, "eigen det")
+
+
+def test_sweep_equals_separate_handles_and_fast_mode(oracle, golden_dir):
+    """Same bits as one storm_solver per system, also in the FMA build (where the oracle is not the yardstick; there
+    the single handle is pinned to the kernel the sweep uses, because contraction differs from kernel to kernel)."""
+    import storm_amd
+    models = [rotating(oracle, golden_dir, "tams", rot) for rot in (0.0, 0.05, 0.1)]
+    grid = models[0].field("r_coord")
+    cfg = [(0, 2, 0), (1, 2, 1), (2, 1, -1), (1, 0, 0), (2, 3, 0)]
+    solvers = [oracle.Solver(models[i], ell, m, "colloc4", grid) for i, ell, m in cfg]
+    grids = [oracle.linspace(1.0, 6.0 + k, 120 + 7 * k) for k in range(len(cfg))]
+    ulp = oracle.relative_to_ulp(1e-8)
+    for arith in (0, 1):
+        sweep = sweep_from_oracle(solvers)
+        sweep.set_option("arithmetic", arith)
+        got = sweep.scan_and_optimize(grids, ulp)
+        roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+        vecs = sweep.eigenvector(roots)
+        for k, o in enumerate(solvers):
+            h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+            h.set_option("arithmetic", arith)
+            if arith:
+                h.set_option("path", 4)  # FMA contraction differs between kernels: compare like with like
+            ref, rdets, rinv = h.scan_and_optimize(grids[k], ulp)
+            assert same_bits(got[k][1], rdets) and got[k][2] == rinv, (arith, k)
+            assert same_brackets(ref, got[k][0]), (arith, k)
+            rdet, rvec = h.eigenvector(roots[k])
+            assert same_bits(vecs[k][1], rvec) and same_bits(vecs[k][0], rdet), (arith, k)
+        for lanes in (16, 32):
+            sweep.set_option("hex_lanes", lanes)
+            again = sweep.det(grids)
+            for k in range(len(cfg)):
+                assert same_bits(again[k], got[k][1]), (arith, lanes, k)
+
+
+def test_sweep_modes_through_host_mirror(oracle, golden_dir):
+    """SolverSweep of the host mirror (one shared interpolation per model) + post-processing of all modes in one pass,
+    against the oracle's per-system scan -> eigenvector -> post-process chain."""
+    from storm_amd import host
+    rots = [0.0, 0.05, 0.1]
+    lm = [(0, 0), (1, 0), (2, 1), (2, -2)]
+    hmodels, omodels = [], []
+    for rot in rots:
+        hm = host.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_zams.npz"))
+        om = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_zams.npz"))
+        hm.set_rotation_constant(rot)
+        om.set_rotation_constant(rot)
+        hmodels.append(hm)
+        omodels.append(om)
+    grid = hmodels[0].field("r_coord")
+    systems = [(hmodels[i], ell, m) for i in range(len(rots)) for ell, m in lm]
+    sweep = host.SolverSweep(systems, "colloc4", grid)
+    assert sweep.n_sys == 12 and sweep.n_int == grid.size - 1
+    grids = [host.linspace(2.0, 14.0, 90)] * sweep.n_sys
+    res = sweep.scan_and_optimize(grids, host.Precision.Relative(1e-8))
+    roots = [np.array([b["root"] for b in br]) for br, _ in res]
+    posts = [host.PostProcessor(hmodels[i].eval(grid)) for i in range(len(rots))]
+    per_sys_posts = [posts[i] for i in range(len(rots)) for _ in lm]
+    ids_only = sweep.modes(per_sys_posts, roots)
+    full = sweep.modes(per_sys_posts, roots, want_fields=True)
+    vecs = sweep.eigenvector(roots)
+    u = 0
+    for i in range(len(rots)):
+        for ell, m in lm:
+            o = oracle.Solver(omodels[i], ell, m, "colloc4", grid)
+            ref, _, rinv = o.scan_and_optimize(grids[u], oracle.relative_to_ulp(1e-8), threads=16)
+            assert same_brackets(ref, res[u][0]) and res[u][1] == rinv, u
+            _, rvec = o.eigenvector(roots[u], threads=16)
+            assert same_bits(vecs[u], rvec), u
+            rp = omodels[i].postprocess(ell, m, roots[u], rvec, threads=16)
+            assert rp["ids"].tolist() == ids_only[u]["ids"].tolist() == full[u]["ids"].tolist(), u
+            assert rp["n_nodes"].tolist() == full[u]["n_nodes"].tolist(), u
+            for a, b in zip(rp["nodes"], full[u]["nodes"]):
+                assert same_bits(a, b), u
+            assert same_bits(rp["fields"], full[u]["fields"]), u
+            u += 1
+
+
+def test_sweep_chunked_eigenvectors(oracle, golden_dir):
+    """A staging cap smaller than the mode count: chunks cut through systems and classes."""
+    models = [rotating(oracle, golden_dir, "zams", rot) for _, _, rot in MIXED[:5]]
+    grid = models[0].field("r_coord")
+    solvers = [oracle.Solver(mdl, ell, m, "colloc2", grid) for mdl, (ell, m, _) in zip(models, MIXED)]
+    sweep = sweep_from_oracle(solvers)
+    grids = [oracle.linspace(2.0, 16.0, 60)] * len(solvers)
+    got = sweep.scan_and_optimize(grids, 4)
+    roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+    assert sum(r.size for r in roots) > 12
+    per_mode = (sweep.n_int * 16 + sweep.n_int * 22 + 6 + (sweep.n_int + 1) * 4) * 8
+    sweep.set_option("steps_bytes_max", 5 * per_mode)
+    vecs = sweep.eigenvector(roots)
+    for k, o in enumerate(solvers):
+        _, rvec = o.eigenvector(roots[k], threads=16)
+        assert same_bits(vecs[k][1], rvec), k
+
+
+def test_sweep_argument_errors(oracle, oracle_models):
+    import ctypes as C
+    import storm_amd
+    from storm_amd import ffi
+    model = oracle_models("zams")
+    grid = model.field("r_coord")
+    a = oracle.Solver(model, 1, 0, "colloc4", grid)
+    b = oracle.Solver(model, 1, 0, "colloc2", grid)
+    c = oracle.Solver(model, 1, 0, "colloc4", grid[::2])
+    L = ffi.load_library()
+    with pytest.raises(storm_amd.StormError, match="share the scheme"):
+        descs = (ffi.SystemDesc * 2)()
+        keep = []
+        for k, o in enumerate((a, b)):
+            s = o.system()
+            arrs = [np.ascontiguousarray(s[q], dtype=np.float64) for q in ("u", "v_gamma", "a_star", "c1", "rot", "delta_over_x")]
+            keep.append(arrs)
+            descs[k] = ffi.SystemDesc(o.scheme, o.ell, o.m, o.n_int, o.p, *[x.ctypes.data_as(C.POINTER(C.c_double)) for x in arrs],
+                                      s["inner_c1"], s["inner_rot"], s["outer_u"])
+        h = C.c_void_p()
+        ffi._check(L.storm_sweep_create(descs, 2, C.byref(h)))
+    with pytest.raises(ValueError):
+        ffi.HipSweep(a.scheme, [(1, 0, a.system()), (1, 0, c.system())], a.n_int, a.p)
+    with pytest.raises(storm_amd.StormError, match="at least one"):
+        ffi.HipSweep(a.scheme, [], a.n_int, a.p)
+    sweep = ffi.HipSweep(a.scheme, [(1, 0, a.system())], a.n_int, a.p)
+    with pytest.raises(storm_amd.StormError, match="unknown option"):
+        sweep.set_option("path", 1)
+    # bad offsets
+    off = np.array([1, 3], dtype=np.uintp)
+    f = np.array([1.0, 2.0, 3.0])
+    out = np.empty(3)
+    rc = L.storm_sweep_det(sweep._h, off.ctypes.data_as(C.POINTER(C.c_size_t)), f.ctypes.data_as(C.POINTER(C.c_double)),
+                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc != 0 and b"offsets[0]" in L.storm_last_error()
+    # capacity: the offsets are still filled in
+    grid_f = oracle.linspace(1.0, 12.0, 80)
+    off = np.array([0, grid_f.size], dtype=np.uintp)
+    ooff = np.zeros(2, dtype=np.uintp)
+    br = (ffi.Bracket * 1)()
+    rc = L.storm_sweep_scan_and_optimize(sweep._h, off.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                         grid_f.ctypes.data_as(C.POINTER(C.c_double)), 4, br, 1,
+                                         ooff.ctypes.data_as(C.POINTER(C.c_size_t)), None, None, None)
+    ref, _, _ = a.scan_and_optimize(grid_f, 4, threads=8)
+    assert rc != 0 and int(ooff[1]) == len(ref) > 1
