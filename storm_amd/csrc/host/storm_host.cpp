@@ -484,11 +484,18 @@ std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes(const std:
     if (!posts[u] && off[u + 1] > off[u]) throw std::runtime_error("SolverSweep::modes: null PostProcessor");
     if (posts[u]) handles[u] = posts[u]->handle();
   }
-  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes(n * np);
+  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes;
   std::vector<storm_mode_id> ids(n ? n : 1);
-  const int rc = storm_sweep_modes(h_, handles.data(), off.data(), flat.data(), nullptr, nullptr,
-                                   want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), np);
-  if (rc != STORM_OK) raise_abi("storm_sweep_modes", rc);
+  size_t cap = std::min(np, size_t(256));  // see kNodeCapFirst
+  for (;; cap = np) {
+    nodes.resize(n * cap);
+    const int rc = storm_sweep_modes(h_, handles.data(), off.data(), flat.data(), nullptr, nullptr,
+                                     want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), cap);
+    if (rc != STORM_OK) raise_abi("storm_sweep_modes", rc);
+    bool fits = true;
+    for (size_t k = 0; k < n; ++k) fits = fits && ids[k].n_nodes <= cap;
+    if (fits || cap == np) break;
+  }
   std::vector<std::vector<Rotating1DPostprocessing>> res(size());
   for (size_t u = 0; u < size(); ++u) {
     const size_t a = off[u], cnt = off[u + 1] - off[u];
@@ -496,8 +503,8 @@ std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes(const std:
     const std::vector<double> f(want_fields ? fields.begin() + a * STORM_POST_FIELDS * np : fields.begin(),
                                 want_fields ? fields.begin() + (a + cnt) * STORM_POST_FIELDS * np : fields.begin());
     const std::vector<storm_mode_id> id(ids.begin() + a, ids.begin() + a + cnt);
-    const std::vector<double> nd(nodes.begin() + a * np, nodes.begin() + (a + cnt) * np);
-    res[u] = posts[u]->unpack(cnt, f, id, nd, np);
+    const std::vector<double> nd(nodes.begin() + a * cap, nodes.begin() + (a + cnt) * cap);
+    res[u] = posts[u]->unpack(cnt, f, id, nd, cap);
   }
   return res;
 }
@@ -522,8 +529,8 @@ std::vector<Rotating1DPostprocessing> PostProcessor::unpack(size_t n, const std:
   std::vector<Rotating1DPostprocessing> out(n);
   for (size_t k = 0; k < n; ++k) {
     Rotating1DPostprocessing& r = out[k];
-    r.x = x_;
     if (!fields.empty()) {
+      r.x = x_;  // (ids-only results carry no per-point arrays at all)
       std::vector<double>* dst[STORM_POST_FIELDS] = {&r.y1, &r.y2, &r.y3, &r.y4, &r.xi_r, &r.xi_h, &r.xi_tn, &r.xi_tp,
                                                      &r.psi, &r.dpsi, &r.rho, &r.p, &r.chi};
       for (int f = 0; f < STORM_POST_FIELDS; ++f) {
@@ -559,16 +566,27 @@ std::vector<Rotating1DPostprocessing> PostProcessor::post_process(const std::vec
   return unpack(n, fields, ids, nodes, np);
 }
 
+namespace {
+// Radial nodes come back as [mode][cap]; a mode has a few to a few hundred of them, not n_pts.  Start with a small
+// capacity and repeat the call with the full one only if some mode has more (n_nodes is always the true count).
+constexpr size_t kNodeCapFirst = 256;
+}  // namespace
+
 std::vector<Rotating1DPostprocessing> PostProcessor::modes(const ErasedSolver& solver, const std::vector<double>& roots,
                                                            bool want_fields) const {
   const size_t n = roots.size(), np = x_.size();
   if (n == 0) return {};
-  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes(n * np);
+  std::vector<double> fields(want_fields ? n * STORM_POST_FIELDS * np : 0), nodes;
   std::vector<storm_mode_id> ids(n);
-  const int rc = storm_modes_batch(solver.handle(), h_, roots.data(), n, nullptr, nullptr,
-                                   want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), np);
-  if (rc != STORM_OK) raise_abi("storm_modes_batch", rc);
-  return unpack(n, fields, ids, nodes, np);
+  for (size_t cap = std::min(np, kNodeCapFirst);; cap = np) {
+    nodes.resize(n * cap);
+    const int rc = storm_modes_batch(solver.handle(), h_, roots.data(), n, nullptr, nullptr,
+                                     want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), cap);
+    if (rc != STORM_OK) raise_abi("storm_modes_batch", rc);
+    bool fits = true;
+    for (const storm_mode_id& id : ids) fits = fits && id.n_nodes <= cap;
+    if (fits || cap == np) return unpack(n, fields, ids, nodes, cap);
+  }
 }
 
 // ---- perturb_structure (perturbed.rs:324-460) ----

@@ -115,9 +115,11 @@ PDEV PointFields point_fields(const PostModelDev& md, const PostParams& q, doubl
 }
 
 __global__ __launch_bounds__(256) void post_terms_kernel(PostModelDev md, PostParams q, const double* __restrict__ freq,
-                                                         const double* __restrict__ vec, double* __restrict__ terms) {
+                                                         const double* __restrict__ vec, double* __restrict__ terms,
+                                                         const PostSystem* __restrict__ systems, const int* __restrict__ mode_sys) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t k = blockIdx.y;
+  if (systems) { const PostSystem& ps = systems[mode_sys[k]]; md = ps.model; q = ps.par; }  // block-uniform
   if (i >= md.n_pts) return;
   const PointFields f = point_fields(md, q, freq[k], vec + k * md.n_pts * 4, i);
   terms[k * md.n_pts + i] = f.term;
@@ -125,9 +127,11 @@ __global__ __launch_bounds__(256) void post_terms_kernel(PostModelDev md, PostPa
 
 __global__ __launch_bounds__(256) void post_fields_kernel(PostModelDev md, PostParams q, const double* __restrict__ freq,
                                                           const double* __restrict__ vec, const double* __restrict__ scale,
-                                                          double* __restrict__ fields) {
+                                                          double* __restrict__ fields, const PostSystem* __restrict__ systems,
+                                                          const int* __restrict__ mode_sys) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t k = blockIdx.y;
+  if (systems) { const PostSystem& ps = systems[mode_sys[k]]; md = ps.model; q = ps.par; }
   if (i >= md.n_pts) return;
   const PointFields f = point_fields(md, q, freq[k], vec + k * md.n_pts * 4, i);
   const double sc = scale[k];
@@ -141,10 +145,12 @@ constexpr int kSumTile = 1024;  // terms staged per round of the ordered sum (16
 // One wave per mode.
 __global__ __launch_bounds__(64) void post_modes_kernel(PostModelDev md, PostParams q, const double* __restrict__ vec,
                                                         const double* __restrict__ terms, double* __restrict__ scale_out,
-                                                        long long* __restrict__ ids, double* __restrict__ nodes, size_t node_cap) {
+                                                        long long* __restrict__ ids, double* __restrict__ nodes, size_t node_cap,
+                                                        const PostSystem* __restrict__ systems, const int* __restrict__ mode_sys) {
   __shared__ __attribute__((aligned(16))) double tile[2][kSumTile];
   const int lane = threadIdx.x;
   const size_t k = blockIdx.x;
+  if (systems) { const PostSystem& ps = systems[mode_sys[k]]; md = ps.model; q = ps.par; }
   const size_t np = md.n_pts;
   const double* __restrict__ tm = terms + k * np;
   // ---- norm: 0 + t[1] + t[2] + ... in index order (src/postprocessing.rs:97,167-170) ----
@@ -361,14 +367,14 @@ hipError_t launch_postprocess(const PostArgs& a) {
   if (a.n == 0) return hipSuccess;
   if (a.n > 65535 || a.model.n_pts < 2) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((a.model.n_pts + 255) / 256), (unsigned)a.n, 1);
-  post_terms_kernel<<<grid, 256, 0, a.stream>>>(a.model, a.par, a.freq, a.vec, a.terms);
+  post_terms_kernel<<<grid, 256, 0, a.stream>>>(a.model, a.par, a.freq, a.vec, a.terms, a.systems, a.mode_sys);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  post_modes_kernel<<<(unsigned)a.n, 64, 0, a.stream>>>(a.model, a.par, a.vec, a.terms, a.scale, a.ids, a.nodes, a.node_cap);
+  post_modes_kernel<<<(unsigned)a.n, 64, 0, a.stream>>>(a.model, a.par, a.vec, a.terms, a.scale, a.ids, a.nodes, a.node_cap, a.systems, a.mode_sys);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.fields) {
-    post_fields_kernel<<<grid, 256, 0, a.stream>>>(a.model, a.par, a.freq, a.vec, a.scale, a.fields);
+    post_fields_kernel<<<grid, 256, 0, a.stream>>>(a.model, a.par, a.freq, a.vec, a.scale, a.fields, a.systems, a.mode_sys);
     e = hipGetLastError();
   }
   return e;

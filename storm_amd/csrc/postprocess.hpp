@@ -26,9 +26,19 @@ struct PostParams {
   double lambda, lambda_n1, lambda_p1, q_hd_n, q_hd_p, q_h_n, q_h_p, mf, ellf;
 };
 
+// One entry per system when the modes of several systems share a launch (storm_sweep_modes).
+struct PostSystem {
+  PostModelDev model;
+  PostParams par;
+};
+
 struct PostArgs {
   PostModelDev model;
   PostParams par;
+  // several systems per launch: mode k belongs to systems[mode_sys[k]] (device arrays; every model has the same n_pts,
+  // given in `model.n_pts`); systems == nullptr: the one (model, par) above
+  const PostSystem* systems = nullptr;
+  const int* mode_sys = nullptr;
   const double* freq;   // device [n]
   const double* vec;    // device [n][n_pts*4], raw eigenvectors (last component 1)
   size_t n;

@@ -1174,6 +1174,7 @@ struct storm_sweep {
   DevBuf<int> d_sys, d_swaps, d_flags;
   DevBuf<double> d_terms, d_scale, d_fields, d_nodes;  // post-processing scratch (storm_sweep_modes)
   DevBuf<long long> d_ids;
+  DevBuf<PostSystem> d_post_table;                     // (model, ell, m) of every system, internal order
   PinnedBuf h_in, h_out, h_flags;
   int arith = 0, hex_lanes = 0;
   size_t steps_bytes_max = size_t(4) << 30;
@@ -1465,7 +1466,7 @@ void storm_sweep_destroy(storm_sweep* q) {
   if (q->sync_marker) (void)hipEventDestroy(q->sync_marker);
   q->tab.release(); q->d_table.release(); q->d_freq.release(); q->d_det.release(); q->d_steps.release(); q->d_upper.release();
   q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
-  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
+  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
   (void)hipSetDevice(prev);
   delete q;
 }
@@ -1627,33 +1628,42 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
       if (want_fields) q->d_fields.reserve(chunk * kPostFields * np, q->stream);
       if (ncap) q->d_nodes.reserve(chunk * ncap, q->stream);
     }
+    std::vector<PostSystem> table;  // outlives the copy below (the stream is synchronised before this call returns)
+    if (post) {
+      // one (model, ell, m) entry per system; the kernels pick the entry of each mode (its system's internal position)
+      table.resize(S);
+      for (size_t p = 0; p < S; ++p) {
+        const size_t u = q->order[p];
+        table[p] = PostSystem{};
+        if (offsets[u + 1] == offsets[u]) continue;
+        storm_postproc* pp = posts[u];
+        {
+          std::lock_guard<std::mutex> lock_p(pp->mu);
+          ensure_model(pp, q->stream);
+        }
+        table[p].model = pp->model;
+        table[p].par = post_params(q->ell[u], q->m[u]);
+      }
+      q->d_post_table.reserve(S, q->stream);
+      hip_check(hipMemcpyAsync(q->d_post_table.p, table.data(), S * sizeof(PostSystem), hipMemcpyHostToDevice, q->stream),
+                "post-processing table H2D");
+    }
     std::vector<long long> h_ids;
     for (size_t off = 0; off < n; off += chunk) {
       const size_t k = std::min(chunk, n - off);
       set_eigen_chunk(q, fr.data() + off, pos.data() + off, k);
       if (post) {
-        // one (ell, m, model) per system: its modes are a contiguous run of the chunk
-        for (size_t a = 0; a < k;) {
-          size_t b = a;
-          while (b < k && pos[off + b] == pos[off + a]) ++b;
-          const size_t u = q->order[size_t(pos[off + a])];
-          storm_postproc* pp = posts[u];
-          {
-            std::lock_guard<std::mutex> lock_p(pp->mu);
-            ensure_model(pp, q->stream);
-          }
-          PostArgs pa;
-          pa.model = pp->model; pa.par = post_params(q->ell[u], q->m[u]);
-          pa.freq = q->d_freq.p + a; pa.vec = q->d_vec.p + a * len; pa.n = b - a;
-          pa.terms = q->d_terms.p + a * np; pa.scale = q->d_scale.p + a;
-          pa.fields = want_fields ? q->d_fields.p + a * kPostFields * np : nullptr;
-          pa.ids = q->d_ids.p + a * 4;
-          pa.nodes = ncap ? q->d_nodes.p + a * ncap : nullptr;
-          pa.node_cap = ncap; pa.stream = q->stream;
-          hip_check(launch_postprocess(pa), "postprocess launch");
-          q->stats.launches += want_fields ? 3 : 2;
-          a = b;
-        }
+        PostArgs pa;
+        pa.model.tab = nullptr; pa.model.n_pts = np; pa.par = PostParams{};
+        pa.systems = q->d_post_table.p; pa.mode_sys = q->d_sys.p;
+        pa.freq = q->d_freq.p; pa.vec = q->d_vec.p; pa.n = k;
+        pa.terms = q->d_terms.p; pa.scale = q->d_scale.p;
+        pa.fields = want_fields ? q->d_fields.p : nullptr;
+        pa.ids = q->d_ids.p;
+        pa.nodes = ncap ? q->d_nodes.p : nullptr;
+        pa.node_cap = ncap; pa.stream = q->stream;
+        hip_check(launch_postprocess(pa), "postprocess launch");
+        q->stats.launches += want_fields ? 3 : 2;
       }
       // results to the host: staged in pinned memory in internal order, scattered to the caller's order
       const size_t nv = vec_out ? k * len : 0, nf = want_fields ? k * kPostFields * np : 0, nn = ncap ? k * ncap : 0;

@@ -4,11 +4,13 @@
 // build: g++ -O2 -std=c++17 -pthread -o tools/many_scans.bin tools/many_scans.cpp -Lstorm_amd/lib -lstorm_host -lstorm_hip
 //        -Wl,-rpath,'$ORIGIN/../storm_amd/lib'
 // run:   tools/many_scans.bin model.bin [scans=64] [steps=300] [scheme=1] [threads...]
+//        a negative thread count -B runs the jobs as SolverSweeps of B systems each (storm_sweep)
 //        model.bin = u64 n, f64 R_star, f64 M_star, then r, M_r, rho, P, Gamma_1, N2, Omega_rot (n doubles each)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -75,7 +77,58 @@ int main(int argc, char** argv) {
     }
   };
   { Phases warm; job(0, warm); }
+  // a negative "thread count" -B runs the same jobs as SolverSweeps of B systems each (one host thread):
+  // every system of a sweep advances in lock-step, one launch per phase for all of them
+  auto sweep_run = [&](size_t batch) {
+    const auto t0 = Clock::now();
+    double t_new = 0, t_scan = 0, t_post = 0, t_modes = 0;
+    size_t found = 0;
+    for (size_t first = 0; first < scans; first += batch) {
+      const size_t cnt = std::min(batch, scans - first);
+      auto t = Clock::now();
+      // one model per rotation rate, shared by its (ell, m) systems
+      std::vector<std::unique_ptr<DiscreteModel>> models;
+      std::vector<std::unique_ptr<LinearInterpolator>> cms;
+      std::vector<size_t> model_of(cnt);
+      std::vector<SweepSystem> systems(cnt);
+      size_t last_rate = size_t(-1);
+      for (size_t j = 0; j < cnt; ++j) {
+        const size_t k = first + j, rate = k / 8;
+        if (rate != last_rate) {
+          models.push_back(std::make_unique<DiscreteModel>(base));
+          const double rot = 0.01 + 0.002 * double(rate);
+          for (double& r : models.back()->dimensionless.rot) r = rot;
+          cms.push_back(std::make_unique<LinearInterpolator>(*models.back()));
+          last_rate = rate;
+        }
+        model_of[j] = cms.size() - 1;
+        systems[j] = SweepSystem{cms.back().get(), Rotating1D::make(combos[k % 8].first, combos[k % 8].second)};
+      }
+      SolverSweep sweep(systems, DifferenceSchemes(scheme), grid);
+      t_new += ms_since(t); t = Clock::now();
+      const auto res = sweep.scan_and_optimize(std::vector<std::vector<double>>(cnt, freqs), Precision::Relative(1e-8));
+      t_scan += ms_since(t); t = Clock::now();
+      std::vector<std::unique_ptr<PostProcessor>> pps;
+      for (auto& cm : cms) pps.push_back(std::make_unique<PostProcessor>(cm->eval(grid)));
+      std::vector<const PostProcessor*> posts(cnt);
+      std::vector<std::vector<double>> roots(cnt);
+      for (size_t j = 0; j < cnt; ++j) {
+        posts[j] = pps[model_of[j]].get();
+        for (const BracketResult& b : res[j]) roots[j].push_back(b.root);
+      }
+      t_post += ms_since(t); t = Clock::now();
+      const auto ids = sweep.modes(posts, roots, false);
+      t_modes += ms_since(t);
+      for (const auto& v : ids) found += v.size();
+    }
+    const double wall = ms_since(t0);
+    std::printf("sweep %4zu: %8.1f ms for %zu scans x %zu frequencies = %6.3f ms/scan, %zu modes, %7.0f modes/s | per-scan phases (ms): "
+                "sweep-create %.3f scan %.3f postproc-create %.3f modes %.3f\n", batch, wall, scans, steps, wall / scans, found,
+                found / wall * 1e3, t_new / scans, t_scan / scans, t_post / scans, t_modes / scans);
+    std::fflush(stdout);
+  };
   for (int th : thread_counts) {
+    if (th < 0) { sweep_run(size_t(-th)); continue; }
     std::atomic<size_t> next{0};
     std::vector<Phases> per(th);
     const auto t0 = Clock::now();
