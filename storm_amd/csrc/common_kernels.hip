@@ -425,16 +425,277 @@ __global__ __launch_bounds__(64) void eigen_backsub_kernel(size_t n_int, size_t 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane-per-mode variants of the two eigenvector kernels, for launches with thousands of modes (storm_sweep: every mode of
+// every system of a rotation sweep).  The wave-per-mode kernels above spend a whole wave's issue slot on 8 useful lanes
+// and a lone wave already saturates its SIMD (one FP64 VALU instruction per 4 cycles), so beyond ~1 wave per SIMD their
+// time grows linearly with the number of modes.  Here every lane carries one mode completely in registers (the 6 x 8
+// band, 48 doubles): no cross-lane traffic, ~700 instructions per interval for 64 modes instead of ~350 for one.  Same
+// operations in the same order per mode (row_pivot!/column_pivot!/sweep!, src/solver.rs:163-269), so the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// One pivot step of the band held by this lane: rows K..ROWS-1, columns K..COLS-1 (entries left of the pivot column are
+// never read again).  fac[0 .. COLS-K-2] receives the normalised pivot row.
+template <int ROWS, int COLS, int K, bool SEARCH>
+SDEV void lane_pivot(double (&b)[6][8], double& det, double* __restrict__ fac) {
+  double prow[COLS];
+  if constexpr (SEARCH) {
+    int idx = K;
+    double best = __builtin_fabs(b[K][K]);
+#pragma unroll
+    for (int r = K + 1; r < ROWS; ++r) {
+      const double v = __builtin_fabs(b[r][K]);
+      const bool gt = v > best;  // strict: the first maximum wins, NaN never does
+      idx = gt ? r : idx;
+      best = gt ? v : best;
+    }
+    // the row exchange, by selects (the row index differs from lane to lane)
+#pragma unroll
+    for (int c = K; c < COLS; ++c) {
+      double pv = b[K][c];
+#pragma unroll
+      for (int r = K + 1; r < ROWS; ++r) pv = (idx == r) ? b[r][c] : pv;
+      prow[c] = pv;
+    }
+#pragma unroll
+    for (int r = K + 1; r < ROWS; ++r)
+#pragma unroll
+      for (int c = K; c < COLS; ++c) b[r][c] = (idx == r) ? b[K][c] : b[r][c];
+    det = det * (idx != K ? -1.0 : 1.0);
+  } else {
+#pragma unroll
+    for (int c = K; c < COLS; ++c) prow[c] = b[K][c];
+  }
+  const double pivot = prow[K];
+  det = det * pivot;
+  const double pinv = 1.0 / pivot;
+#pragma unroll
+  for (int c = K + 1; c < COLS; ++c) fac[c - K - 1] = prow[c] * pinv;
+#pragma unroll
+  for (int r = K + 1; r < ROWS; ++r) {
+    const double m = b[r][K] * pinv;
+#pragma unroll
+    for (int c = K + 1; c < COLS; ++c) b[r][c] = b[r][c] - prow[c] * m;
+  }
+}
+
+// column_pivot! for pivot K of the first interval, lane-local.  Returns the column exchanged with K (K if none).
+template <int K>
+SDEV int lane_column_swap(double (&b)[6][8], double& det) {
+  int idx = K;
+  double best = __builtin_fabs(b[K][K]);
+#pragma unroll
+  for (int c = K + 1; c < 8; ++c) {
+    const double v = __builtin_fabs(b[K][c]);
+    const bool gt = v > best;
+    idx = gt ? c : idx;
+    best = gt ? v : best;
+  }
+#pragma unroll
+  for (int r = K; r < 6; ++r) {
+    const double from_k = b[r][K];
+    double from_max = from_k;
+#pragma unroll
+    for (int c = K + 1; c < 8; ++c) from_max = (idx == c) ? b[r][c] : from_max;
+    b[r][K] = from_max;
+#pragma unroll
+    for (int c = K + 1; c < 8; ++c) b[r][c] = (idx == c) ? from_k : b[r][c];
+  }
+  det = det * (idx != K ? -1.0 : 1.0);
+  return idx;
+}
+
+template <bool ELL0>
+__global__ __launch_bounds__(64) void eigen_forward_lanes_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
+                                                                 const double* __restrict__ steps,
+                                                                 double* __restrict__ upper, int* __restrict__ swaps,
+                                                                 double* __restrict__ det_out,
+                                                                 const SystemDev* __restrict__ table,
+                                                                 const int* __restrict__ sys_index) {
+  const size_t m_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = m_raw < n;
+  const size_t m = live ? m_raw : n - 1;  // surplus lanes repeat the last mode and store nothing
+  const size_t n_int = s0.n_int;          // shared by every system of the launch
+  SystemDev s = s0;
+  if (table) {  // only the boundary scalars differ from lane to lane
+    const SystemDev* __restrict__ mine = table + sys_index[m];
+    s.ell = mine->ell; s.inner_c1 = mine->inner_c1; s.inner_rotm = mine->inner_rotm; s.outer_u = mine->outer_u;
+  }
+  const double f = freq[m];
+  // factors go out mode-fastest, [interval*22 + entry][mode] (row length n_pad = the grid's lane count): one coalesced
+  // 512-B store per entry instead of 64 lines touched by every store; surplus lanes write their own (unused) columns
+  const size_t n_pad = (size_t)gridDim.x * 64;
+  double* __restrict__ up = upper + m_raw;
+  const double2* __restrict__ st = reinterpret_cast<const double2*>(steps + m * n_int * 16);
+  double b[6][8];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b[r][c] = 0.0;
+  // inner boundary rows (reference src/system/adiabatic.rs:154-183)
+  b[0][0] = inner_00<ELL0>(s, f);
+  b[0][1] = -s.ell; b[0][2] = -s.ell;
+  b[1][2] = s.ell;  b[1][3] = -1.0;
+  double det = 1.0;
+  int sw0 = 0, sw1 = 1;
+  double2 nxt[8];  // the step matrix of the next interval, row-major, fetched one interval (~3000 cycles) ahead
+  if (n_int > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nxt[q] = st[q];
+  }
+  for (size_t i = 0; i < n_int; ++i) {
+    // rows 2..5 <- [L | -I]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      b[r + 2][0] = nxt[r * 2].x; b[r + 2][1] = nxt[r * 2].y; b[r + 2][2] = nxt[r * 2 + 1].x; b[r + 2][3] = nxt[r * 2 + 1].y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[r + 2][c + 4] = (r == c) ? -1.0 : 0.0;
+    }
+    {
+      const size_t ni = i + 1 < n_int ? i + 1 : i;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) nxt[q] = st[ni * 8 + q];
+    }
+    double fac[22];
+    if (i == 0) {
+      sw0 = lane_column_swap<0>(b, det);
+      lane_pivot<6, 8, 0, false>(b, det, fac + 0);
+      sw1 = lane_column_swap<1>(b, det);
+      lane_pivot<6, 8, 1, false>(b, det, fac + 7);
+    } else {
+      lane_pivot<6, 8, 0, true>(b, det, fac + 0);
+      lane_pivot<6, 8, 1, true>(b, det, fac + 7);
+    }
+    lane_pivot<6, 8, 2, true>(b, det, fac + 13);
+    lane_pivot<6, 8, 3, true>(b, det, fac + 18);
+    {
+      double* __restrict__ dst = up + i * 22 * n_pad;
+#pragma unroll
+      for (int q = 0; q < 22; ++q) dst[q * n_pad] = fac[q];
+    }
+    // the two untouched rows move up: B[i][j] = B[i+4][j+4], right half cleared
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      b[0][c] = b[4][c + 4]; b[1][c] = b[5][c + 4];
+      b[0][c + 4] = 0.0; b[1][c + 4] = 0.0;
+    }
+  }
+  // outer boundary rows (reference src/system/adiabatic.rs:185-208) and the closing 4x4
+  b[2][0] = 1.0; b[2][1] = -1.0; b[2][2] = 0.0; b[2][3] = 0.0;
+  b[3][0] = s.outer_u; b[3][1] = 0.0; b[3][2] = s.ell + 1.0; b[3][3] = 1.0;
+  double fin[6];
+  lane_pivot<4, 4, 0, true>(b, det, fin + 0);
+  lane_pivot<4, 4, 1, true>(b, det, fin + 3);
+  lane_pivot<4, 4, 2, true>(b, det, fin + 5);
+  {
+    double* __restrict__ dst = up + n_int * 22 * n_pad;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst[q * n_pad] = fin[q];
+  }
+  if (live) {
+    swaps[m * 2 + 0] = sw0; swaps[m * 2 + 1] = sw1;
+    det_out[m] = det * b[3][3];
+  }
+}
+
+// Back-substitution, one lane per mode (`vec` has room for gridDim.x*64 modes): 22 factors per interval straight from
+// global memory into registers, four
+// intervals ahead (HBM latency is several intervals long), 44 multiply/subtract instructions per interval for 64 modes.
+__global__ __launch_bounds__(64) void eigen_backsub_lanes_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
+                                                                 const int* __restrict__ swaps, double* __restrict__ vec) {
+  const size_t m_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = m_raw < n;
+  const size_t m = live ? m_raw : n - 1;
+  const size_t len = (n_int + 1) * 4;
+  const size_t n_pad = (size_t)gridDim.x * 64;  // factors are mode-fastest, see eigen_forward_lanes_kernel
+  const double* __restrict__ d = upper + m_raw;
+  // Surplus lanes write rows past the last mode (the caller sizes `vec` for the padded count): no branch inside the
+  // loop, so the compiler can count outstanding loads exactly instead of draining them at every join.
+  double* __restrict__ e = vec + m_raw * len;
+  const double* __restrict__ df = d + n_int * 22 * n_pad;
+  const double e3 = 1.0;
+  const double e2 = 0.0 - df[5 * n_pad] * e3;
+  const double e1 = (0.0 - df[4 * n_pad] * e3) - df[3 * n_pad] * e2;
+  const double e0 = ((0.0 - df[2 * n_pad] * e3) - df[1 * n_pad] * e2) - df[0] * e1;
+  {
+    double2* __restrict__ dst = reinterpret_cast<double2*>(e + len - 4);
+    dst[0] = make_double2(e0, e1);
+    dst[1] = make_double2(e2, e3);
+  }
+  double b0 = e3, b1 = e2, b2 = e1, b3 = e0;
+  struct Factors { double2 v[11]; };
+  auto load = [&](long long k) {  // (only called with n_int > 0; indices below 0 re-read interval 0)
+    Factors fc;
+    const double* __restrict__ src = d + (size_t)(k < 0 ? 0 : k) * 22 * n_pad;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) fc.v[q] = make_double2(src[(2 * q) * n_pad], src[(2 * q + 1) * n_pad]);
+    return fc;
+  };
+  auto interval = [&](const Factors& c, size_t k) {  // see eigen_backsub_kernel
+    const double p00 = c.v[10].y * b0, p10 = c.v[8].y * b0, p20 = c.v[6].x * b0, p30 = c.v[3].x * b0;
+    const double p01 = c.v[10].x * b1, p11 = c.v[8].x * b1, p21 = c.v[5].y * b1, p31 = c.v[2].y * b1;
+    const double p02 = c.v[9].y * b2, p12 = c.v[7].y * b2, p22 = c.v[5].x * b2, p32 = c.v[2].x * b2;
+    const double p03 = c.v[9].x * b3, p13 = c.v[7].x * b3, p23 = c.v[4].y * b3, p33 = c.v[1].y * b3;
+    double v0 = 0.0 - p00, v1 = 0.0 - p10, v2 = 0.0 - p20, v3 = 0.0 - p30;
+    v0 = v0 - p01; v1 = v1 - p11; v2 = v2 - p21; v3 = v3 - p31;
+    v0 = v0 - p02; v1 = v1 - p12; v2 = v2 - p22; v3 = v3 - p32;
+    v0 = v0 - p03; v1 = v1 - p13; v2 = v2 - p23; v3 = v3 - p33;
+    const double q10 = c.v[6].y * v0, q20 = c.v[4].x * v0, q30 = c.v[1].x * v0;
+    v1 = v1 - q10; v2 = v2 - q20; v3 = v3 - q30;
+    const double q21 = c.v[3].y * v1, q31 = c.v[0].y * v1;
+    v2 = v2 - q21; v3 = v3 - q31;
+    v3 = v3 - c.v[0].x * v2;
+    double2* __restrict__ dst = reinterpret_cast<double2*>(e + k * 4);
+    dst[0] = make_double2(v3, v2);
+    dst[1] = make_double2(v1, v0);
+    b0 = v0; b1 = v1; b2 = v2; b3 = v3;
+  };
+  if (n_int > 0) {
+    long long k = (long long)n_int;
+    Factors f0 = load(k - 1), f1 = load(k - 2), f2 = load(k - 3), f3 = load(k - 4);
+    while (k >= 4) {
+      // (scheduling barriers: left alone, the compiler sinks the refills towards their first use to save registers,
+      // which is exactly the latency this ring is there to hide)
+      interval(f0, (size_t)(k - 1)); f0 = load(k - 5); __builtin_amdgcn_sched_barrier(0);
+      interval(f1, (size_t)(k - 2)); f1 = load(k - 6); __builtin_amdgcn_sched_barrier(0);
+      interval(f2, (size_t)(k - 3)); f2 = load(k - 7); __builtin_amdgcn_sched_barrier(0);
+      interval(f3, (size_t)(k - 4)); f3 = load(k - 8); __builtin_amdgcn_sched_barrier(0);
+      k -= 4;
+    }
+    if (k >= 1) interval(f0, (size_t)(k - 1));
+    if (k >= 2) interval(f1, (size_t)(k - 2));
+    if (k >= 3) interval(f2, (size_t)(k - 3));
+  }
+  // undo the column pivots of the first interval, last recorded first (this lane's own earlier stores)
+  if (live) {
+    const int s1 = swaps[m * 2 + 1], sw0 = swaps[m * 2 + 0];
+    if (s1 != 1) { const double a = e[s1], bb = e[1]; e[s1] = bb; e[1] = a; }
+    if (sw0 != 0) { const double a = e[sw0], bb = e[0]; e[sw0] = bb; e[0] = a; }
+  }
+}
+
+// `layout`: 0 = by mode count, 1 = one wave per mode, 2 = one lane per mode.
 hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream,
-                        const SystemDev* table, const int* sys_index) {
+                        const SystemDev* table, const int* sys_index, int layout) {
   if (n == 0) return hipSuccess;
-  const unsigned fblocks = (unsigned)n;  // one wave per mode
-  if (ell0) eigen_forward_kernel<true><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
-  else eigen_forward_kernel<false><<<fblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+  // wave per mode: ~4.6 ms per 6199 intervals while every wave has a SIMD to itself (1024 modes), then linear in n;
+  // lane per mode: ~2x that per wave, but for 64 modes
+  // (the two layouts keep `upper` differently, so both kernels of a launch use the same one)
+  const bool fwd_lanes = layout == 2 || (layout == 0 && n >= 1536);
+  const bool back_lanes = fwd_lanes;
+  const unsigned wblocks = (unsigned)n, lblocks = (unsigned)((n + 63) / 64);
+  if (fwd_lanes) {
+    if (ell0) eigen_forward_lanes_kernel<true><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+    else eigen_forward_lanes_kernel<false><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+  } else {
+    if (ell0) eigen_forward_kernel<true><<<wblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+    else eigen_forward_kernel<false><<<wblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  eigen_backsub_kernel<<<(unsigned)n, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
+  if (back_lanes) eigen_backsub_lanes_kernel<<<lblocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
+  else eigen_backsub_kernel<<<wblocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
   return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@
                           double* det_out, hipStream_t stream);                                                   \
   hipError_t launch_eigen(const storm::SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps, \
                           double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream,            \
-                          const storm::SystemDev* table = nullptr, const int* sys_index = nullptr);               \
+                          const storm::SystemDev* table, const int* sys_index, int layout);                       \
   }
 STORM_DECL_COMMON(storm)
 STORM_DECL_COMMON(storm_fast)

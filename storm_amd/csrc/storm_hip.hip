@@ -216,6 +216,7 @@ struct storm_solver {
   size_t quad_min_n = size_t(1) << 62;           // auto: quad kernel from this batch size on (off by default)
   size_t hex_min_n = 512;                        // auto: 16/32-lanes-per-frequency kernel from this batch size on
   int hex_lanes = 0;                             // lanes per frequency of that kernel: 0 = by wave-slot packing, 16, 32
+  int eigen_layout = 0;                          // eigenvector kernels: 0 = by mode count, 1 wave per mode, 2 lane per mode
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
   hipEvent_t sync_marker = nullptr;
@@ -557,8 +558,8 @@ size_t eigen_reserve(storm_solver* s, size_t n) {
   if (chunk > 65535) chunk = 65535;
   s->d_freq.reserve(chunk, s->stream); s->d_det.reserve(chunk, s->stream);
   s->d_steps.reserve(chunk * n_int * 16 + 16, s->stream);
-  s->d_upper.reserve(chunk * ustride, s->stream);
-  s->d_vec.reserve(chunk * len, s->stream);
+  s->d_upper.reserve((chunk + 64) * ustride, s->stream);  // lane-per-mode kernels pad the mode count to 64
+  s->d_vec.reserve((chunk + 64) * len, s->stream);
   s->d_swaps.reserve(chunk * 2, s->stream);
   return chunk;
 }
@@ -570,7 +571,7 @@ void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
   tb.stop();
   ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
   hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
-                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream, nullptr, nullptr), "eigen launch");
+                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream, nullptr, nullptr, s->eigen_layout), "eigen launch");
   te.stop();
   count_launch(s, 3);
   s->stats.eigenvectors += m;
@@ -799,6 +800,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     } else if (k == "hex_lanes") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
       s->hex_lanes = int(value);
+    } else if (k == "eigen_layout") {
+      if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "eigen_layout must be 0 (auto), 1 (wave per mode) or 2 (lane per mode)");
+      s->eigen_layout = int(value);
     } else if (k == "quad_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "quad_min_n must be >= 0");
       s->quad_min_n = size_t(value);
@@ -1176,8 +1180,8 @@ struct storm_sweep {
   DevBuf<long long> d_ids;
   DevBuf<PostSystem> d_post_table;                     // (model, ell, m) of every system, internal order
   PinnedBuf h_in, h_out, h_flags;
-  int arith = 0, hex_lanes = 0;
-  size_t steps_bytes_max = size_t(4) << 30;
+  int arith = 0, hex_lanes = 0, eigen_layout = 0;
+  size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
   storm_stats stats{};
   std::mutex mu;
 };
@@ -1307,8 +1311,8 @@ size_t set_eigen_reserve(storm_sweep* q, size_t n) {
   if (chunk > 65535) chunk = 65535;  // grid.y of build_steps
   q->d_freq.reserve(chunk, q->stream); q->d_det.reserve(chunk, q->stream); q->d_sys.reserve(chunk, q->stream);
   q->d_steps.reserve(chunk * n_int * 16 + 16, q->stream);
-  q->d_upper.reserve(chunk * ustride, q->stream);
-  q->d_vec.reserve(chunk * len, q->stream);
+  q->d_upper.reserve((chunk + 64) * ustride, q->stream);  // lane-per-mode kernels pad the mode count to 64
+  q->d_vec.reserve((chunk + 64) * len, q->stream);
   q->d_swaps.reserve(chunk * 2, q->stream);
   return chunk;
 }
@@ -1334,7 +1338,7 @@ void set_eigen_chunk(storm_sweep* q, const double* freq, const int* pos, size_t 
       hip_check((q->arith ? storm_fast::launch_eigen : storm::launch_eigen)(
                     q->h_table[q->cls_begin[c]], set_class_ell0(c), q->d_freq.p + first, n, steps, q->d_upper.p + first * ustride,
                     q->d_swaps.p + first * 2, q->d_det.p + first, q->d_vec.p + first * len, q->stream, q->d_table.p,
-                    q->d_sys.p + first),
+                    q->d_sys.p + first, q->eigen_layout),
                 "eigen launch");
       q->stats.launches += 3;
     }
@@ -1485,6 +1489,9 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "hex_lanes") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
       q->hex_lanes = int(value);
+    } else if (k == "eigen_layout") {
+      if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "eigen_layout must be 0 (auto), 1 (wave per mode) or 2 (lane per mode)");
+      q->eigen_layout = int(value);
     } else if (k == "steps_bytes_max") {
       if (value < 1) fail(STORM_ERR_INVALID_ARGUMENT, "steps_bytes_max must be positive");
       q->steps_bytes_max = size_t(value);

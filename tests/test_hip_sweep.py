@@ -232,3 +232,41 @@ def test_sweep_argument_errors(oracle, oracle_models):
                                          ooff.ctypes.data_as(C.POINTER(C.c_size_t)), None, None, None)
     ref, _, _ = a.scan_and_optimize(grid_f, 4, threads=8)
     assert rc != 0 and int(ooff[1]) == len(ref) > 1
+
+
+@pytest.mark.parametrize("name,ell,m,rot,scheme", [
+    ("zams", 0, 0, None, "colloc4"), ("zams", 2, 1, 0.1, "colloc2"), ("tams", 1, -1, 0.05, "magnus2"),
+    ("zams", 3, 0, lambda x: 0.05 + 0.1 * np.exp(-3.0 * x), "colloc6")])
+def test_lane_per_mode_eigen_kernels(oracle, golden_dir, name, ell, m, rot, scheme):
+    """The lane-per-mode elimination / back-substitution (picked for launches of >= 1536 modes, forced here) against the
+    oracle: 150 frequencies (three waves, the last one ragged), roots and non-roots alike."""
+    import storm_amd
+    model = rotating(oracle, golden_dir, name, rot)
+    o = oracle.Solver(model, ell, m, scheme, model.field("r_coord"))
+    f = oracle.linspace(0.7, 21.3, 150)
+    rdet, rvec = o.eigenvector(f, threads=16)
+    h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+    for layout in (2, 1):
+        h.set_option("eigen_layout", layout)
+        det, vec = h.eigenvector(f)
+        assert same_bits(det, rdet), layout
+        assert same_bits(vec, rvec), layout
+
+
+def test_lane_per_mode_tiny_grids_and_sweep(oracle):
+    """n_int = 1, 2, 3, 5 (the 4-deep factor prefetch of the back-substitution clamps) and the sweep path with
+    per-lane systems."""
+    import storm_amd
+    from storm_amd import ffi
+    model = oracle.Model.poly0(5.0 / 3.0)
+    for npts in (2, 3, 4, 6, 9):
+        grid = oracle.linspace(0.0, 1.0, npts)
+        solvers = [oracle.Solver(model, ell, 0, "colloc2", grid) for ell in (0, 1, 2, 3)]
+        f = [oracle.linspace(1.0 + ell, 9.0, 5 + ell) for ell in range(4)]
+        sweep = ffi.HipSweep(solvers[0].scheme, [(o.ell, o.m, o.system()) for o in solvers], solvers[0].n_int, solvers[0].p)
+        sweep.set_option("eigen_layout", 2)
+        got = sweep.eigenvector(f)
+        for k, o in enumerate(solvers):
+            rdet, rvec = o.eigenvector(f[k], threads=4)
+            assert same_bits(got[k][1], rvec), (npts, k)
+            assert same_bits(got[k][0], rdet), (npts, k)
