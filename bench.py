@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--arithmetic", choices=["parity", "fast"], default="parity",
                     help="headline arithmetic: parity = bit-identical to the reference (default); fast = FMA build")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the rotation-sweep leg (storm_sweep)")
     ap.add_argument("--single-mode", action="store_true", help="do not also measure the other arithmetic mode")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of N > 1)")
     args = ap.parse_args()
@@ -291,6 +292,43 @@ def main():
                     "radial_orders": [int(ids[0, 2]), int(ids[-1, 2])],
                     "note": "latency-bound at this batch size: one wave per mode sums the norm integrand in index "
                             "order (bit-exact parity), ~0.1 ms regardless of the number of modes"}
+    # Next-row leg (outside the timed region and outside `value`): a rotation sweep of many small
+    # scans, 8 rotation rates x 8 (ell, m) systems x 300 frequencies on the tams model with Colloc4 (the CLI default), in
+    # lock-step through storm_sweep: solver construction + scan + refinement + eigenvectors + mode ids.
+    sweep = None
+    if rank == 0 and not args.no_sweep:
+        combos = [(0, 0), (2, 0), (4, 0), (1, 1), (1, -1), (2, 1), (2, -1), (3, 0)]
+        rates = [0.01 + 0.002 * k for k in range(8)]
+        rmodels = []
+        for rot in rates:
+            mdl = host.Model.from_gsm_npz(npz)
+            mdl.set_rotation_constant(rot)
+            rmodels.append(mdl)
+        systems = [(rmodels[i], ell, m) for i in range(len(rates)) for ell, m in combos]
+        sgrid = host.linspace(1.0, 25.0, 300)
+
+        def sweep_once():
+            t0 = time.perf_counter()
+            sw = host.SolverSweep(systems, "colloc4", grid)
+            t1 = time.perf_counter()
+            r = sw.scan_and_optimize([sgrid] * len(systems), host.Precision.Relative(1e-8))
+            t2 = time.perf_counter()
+            posts = [host.PostProcessor(mdl.eval(grid)) for mdl in rmodels]
+            found = sw.modes([posts[k // len(combos)] for k in range(len(systems))],
+                             [np.array([b["root"] for b in br]) for br, _ in r])
+            t3 = time.perf_counter()
+            return sum(len(x["ids"]) for x in found), (t1 - t0, t2 - t1, t3 - t2), sw.stats()
+
+        sweep_once()
+        n_modes, (t_new, t_scan, t_modes), st = sweep_once()
+        total = t_new + t_scan + t_modes
+        sweep = {"systems": len(systems), "frequencies_per_scan": int(sgrid.size), "scheme": "colloc4", "modes": int(n_modes),
+                 "ms_per_scan": round(total / len(systems) * 1e3, 4), "modes_per_s": round(n_modes / total, 1),
+                 "ms_create_scan_modes": [round(t_new * 1e3, 2), round(t_scan * 1e3, 2), round(t_modes * 1e3, 2)],
+                 "refine_rounds": st["refine_rounds"], "launches": st["launches"],
+                 "note": "all systems advance in lock-step: one launch per phase over every (system, frequency) pair "
+                         "or mode; bit-identical to one handle per system (tests/test_hip_sweep.py); one handle per "
+                         "system on 16 host threads: tools/many_scans.cpp, DESIGN.md section 11"}
     kernel_summary, roofline = res["kernels"], res["roofline"]
 
     if rank == 0:
@@ -308,6 +346,7 @@ def main():
             "modes_per_step": modes, "det_evals": det_evals, "refine_evals": refine,
             "arithmetic": args.arithmetic, "kernels": kernel_summary, "roofline": roofline,
             "post_processing": post,
+            "rotation_sweep": sweep,
         }
         if other is not None:
             oname = "parity" if main_arith else "fast"
