@@ -505,7 +505,9 @@ SDEV int lane_column_swap(double (&b)[6][8], double& det) {
   return idx;
 }
 
-template <bool ELL0>
+// ELL_CLASS: 0 = every mode has ell != 0, 1 = every mode has ell == 0, 2 = per lane (a sweep's modes of all systems in
+// one launch; only the inner boundary depends on it).
+template <int ELL_CLASS>
 __global__ __launch_bounds__(64) void eigen_forward_lanes_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
                                                                  const double* __restrict__ steps,
                                                                  double* __restrict__ upper, int* __restrict__ swaps,
@@ -533,7 +535,12 @@ __global__ __launch_bounds__(64) void eigen_forward_lanes_kernel(SystemDev s0, c
 #pragma unroll
     for (int c = 0; c < 8; ++c) b[r][c] = 0.0;
   // inner boundary rows (reference src/system/adiabatic.rs:154-183)
-  b[0][0] = inner_00<ELL0>(s, f);
+  if constexpr (ELL_CLASS == 2) {
+    const double radial = inner_00<true>(s, f), other = inner_00<false>(s, f);  // (the unused one may be inf/NaN)
+    b[0][0] = (s.ell == 0.0) ? radial : other;
+  } else {
+    b[0][0] = inner_00<ELL_CLASS == 1>(s, f);
+  }
   b[0][1] = -s.ell; b[0][2] = -s.ell;
   b[1][2] = s.ell;  b[1][3] = -1.0;
   double det = 1.0;
@@ -598,30 +605,57 @@ __global__ __launch_bounds__(64) void eigen_forward_lanes_kernel(SystemDev s0, c
   }
 }
 
-// Back-substitution, one lane per mode (`vec` has room for gridDim.x*64 modes): 22 factors per interval straight from
-// global memory into registers, four
+// Back-substitution, one lane per mode: 22 factors per interval straight from global memory into registers, four
 // intervals ahead (HBM latency is several intervals long), 44 multiply/subtract instructions per interval for 64 modes.
+// The result layout is [mode][point][4], i.e. lane-strided by the whole eigenvector: written directly, every store
+// touches 64 lines (measured: half the kernel's time).  So finished points are parked in LDS, 16 points x 4 components
+// per mode, and flushed transposed: one coalesced 512-B store per mode and tile.
+constexpr int kBlTilePoints = 16;
+constexpr int kBlTileRows = kBlTilePoints * 4;  // 64: one row per (point, component), one column per mode
+constexpr int kBlTileStride = 65;               // doubles per row (odd: the transposed read is conflict-free)
+
 __global__ __launch_bounds__(64) void eigen_backsub_lanes_kernel(size_t n_int, size_t n, const double* __restrict__ upper,
                                                                  const int* __restrict__ swaps, double* __restrict__ vec) {
-  const size_t m_raw = (size_t)blockIdx.x * 64 + threadIdx.x;
+  __shared__ double tile[kBlTileRows * kBlTileStride];
+  const int lane = threadIdx.x;
+  const size_t m0 = (size_t)blockIdx.x * 64;
+  const size_t m_raw = m0 + lane;
   const bool live = m_raw < n;
   const size_t m = live ? m_raw : n - 1;
   const size_t len = (n_int + 1) * 4;
   const size_t n_pad = (size_t)gridDim.x * 64;  // factors are mode-fastest, see eigen_forward_lanes_kernel
   const double* __restrict__ d = upper + m_raw;
-  // Surplus lanes write rows past the last mode (the caller sizes `vec` for the padded count): no branch inside the
-  // loop, so the compiler can count outstanding loads exactly instead of draining them at every join.
-  double* __restrict__ e = vec + m_raw * len;
+  const int sw1 = swaps[m * 2 + 1], sw0 = swaps[m * 2 + 0];
+  const size_t modes_here = n - m0 < 64 ? n - m0 : 64;
+  // Point p = (y1..y4)(x_p) of this lane's mode goes to column `lane` of the tile; the tile holding point 0 is the
+  // last one, and the column exchanges of the first interval (entries 0..7 = points 0 and 1) are undone in it.
+  auto flush = [&](size_t p0) {
+    const size_t top = n_int - p0 < (size_t)(kBlTilePoints - 1) ? n_int - p0 : (size_t)(kBlTilePoints - 1);  // last point held
+    const int rows = (int)(top + 1) * 4;
+    if (p0 == 0 && n_int > 0) {  // last recorded first
+      double* col = tile + lane;
+      if (sw1 != 1) { const double a = col[sw1 * kBlTileStride], bb = col[1 * kBlTileStride]; col[sw1 * kBlTileStride] = bb; col[1 * kBlTileStride] = a; }
+      if (sw0 != 0) { const double a = col[sw0 * kBlTileStride], bb = col[0]; col[sw0 * kBlTileStride] = bb; col[0] = a; }
+    }
+    __syncthreads();
+    for (size_t jm = 0; jm < modes_here; ++jm) {
+      const double v = tile[lane * kBlTileStride + jm];
+      if (lane < rows) vec[(m0 + jm) * len + p0 * 4 + lane] = v;
+    }
+    __syncthreads();
+  };
+  auto emit = [&](size_t p, double y1, double y2, double y3, double y4) {
+    double* col = tile + (p % kBlTilePoints) * 4 * kBlTileStride + lane;
+    col[0] = y1; col[kBlTileStride] = y2; col[2 * kBlTileStride] = y3; col[3 * kBlTileStride] = y4;
+    if (p % kBlTilePoints == 0) flush(p);
+  };
+  // closing 4x4 (reference src/solver.rs:107-113)
   const double* __restrict__ df = d + n_int * 22 * n_pad;
   const double e3 = 1.0;
   const double e2 = 0.0 - df[5 * n_pad] * e3;
   const double e1 = (0.0 - df[4 * n_pad] * e3) - df[3 * n_pad] * e2;
   const double e0 = ((0.0 - df[2 * n_pad] * e3) - df[1 * n_pad] * e2) - df[0] * e1;
-  {
-    double2* __restrict__ dst = reinterpret_cast<double2*>(e + len - 4);
-    dst[0] = make_double2(e0, e1);
-    dst[1] = make_double2(e2, e3);
-  }
+  emit(n_int, e0, e1, e2, e3);
   double b0 = e3, b1 = e2, b2 = e1, b3 = e0;
   struct Factors { double2 v[11]; };
   auto load = [&](long long k) {  // (only called with n_int > 0; indices below 0 re-read interval 0)
@@ -645,9 +679,7 @@ __global__ __launch_bounds__(64) void eigen_backsub_lanes_kernel(size_t n_int, s
     const double q21 = c.v[3].y * v1, q31 = c.v[0].y * v1;
     v2 = v2 - q21; v3 = v3 - q31;
     v3 = v3 - c.v[0].x * v2;
-    double2* __restrict__ dst = reinterpret_cast<double2*>(e + k * 4);
-    dst[0] = make_double2(v3, v2);
-    dst[1] = make_double2(v1, v0);
+    emit(k, v3, v2, v1, v0);
     b0 = v0; b1 = v1; b2 = v2; b3 = v3;
   };
   if (n_int > 0) {
@@ -666,35 +698,34 @@ __global__ __launch_bounds__(64) void eigen_backsub_lanes_kernel(size_t n_int, s
     if (k >= 2) interval(f1, (size_t)(k - 2));
     if (k >= 3) interval(f2, (size_t)(k - 3));
   }
-  // undo the column pivots of the first interval, last recorded first (this lane's own earlier stores)
-  if (live) {
-    const int s1 = swaps[m * 2 + 1], sw0 = swaps[m * 2 + 0];
-    if (s1 != 1) { const double a = e[s1], bb = e[1]; e[s1] = bb; e[1] = a; }
-    if (sw0 != 0) { const double a = e[sw0], bb = e[0]; e[sw0] = bb; e[0] = a; }
-  }
 }
 
-// `layout`: 0 = by mode count, 1 = one wave per mode, 2 = one lane per mode.
-hipError_t launch_eigen(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
+// `layout`: 0 = by mode count, 1 = one wave per mode, 2 = one lane per mode.  `ell_class`: 0 = ell != 0 for every mode,
+// 1 = ell == 0 for every mode, 2 = mixed (lane-per-mode kernels only: their one ell-dependent expression is selected
+// per lane, so the modes of every system of a sweep go out in ONE launch).
+bool eigen_uses_lanes(size_t n, int layout) {
+  // wave per mode: ~4.6 ms per 6199 intervals while every wave has a SIMD to itself (1024 modes), then linear in n;
+  // lane per mode: ~2x that per wave, but for 64 modes
+  return layout == 2 || (layout == 0 && n >= 1536);
+}
+hipError_t launch_eigen(const SystemDev& s, int ell_class, const double* freq, size_t n, const double* steps,
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream,
                         const SystemDev* table, const int* sys_index, int layout) {
   if (n == 0) return hipSuccess;
-  // wave per mode: ~4.6 ms per 6199 intervals while every wave has a SIMD to itself (1024 modes), then linear in n;
-  // lane per mode: ~2x that per wave, but for 64 modes
-  // (the two layouts keep `upper` differently, so both kernels of a launch use the same one)
-  const bool fwd_lanes = layout == 2 || (layout == 0 && n >= 1536);
-  const bool back_lanes = fwd_lanes;
+  const bool lanes = eigen_uses_lanes(n, layout);  // (the two layouts keep `upper` differently: both kernels follow it)
+  if (ell_class == 2 && !lanes) return hipErrorInvalidValue;
   const unsigned wblocks = (unsigned)n, lblocks = (unsigned)((n + 63) / 64);
-  if (fwd_lanes) {
-    if (ell0) eigen_forward_lanes_kernel<true><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
-    else eigen_forward_lanes_kernel<false><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+  if (lanes) {
+    if (ell_class == 2) eigen_forward_lanes_kernel<2><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+    else if (ell_class == 1) eigen_forward_lanes_kernel<1><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+    else eigen_forward_lanes_kernel<0><<<lblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
   } else {
-    if (ell0) eigen_forward_kernel<true><<<wblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
+    if (ell_class == 1) eigen_forward_kernel<true><<<wblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
     else eigen_forward_kernel<false><<<wblocks, 64, 0, stream>>>(s, freq, n, steps, upper, swaps, det_out, table, sys_index);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (back_lanes) eigen_backsub_lanes_kernel<<<lblocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
+  if (lanes) eigen_backsub_lanes_kernel<<<lblocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
   else eigen_backsub_kernel<<<wblocks, 64, 0, stream>>>(s.n_int, n, upper, swaps, vec);
   return hipGetLastError();
 }

@@ -570,7 +570,7 @@ void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
   hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
   tb.stop();
   ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
-  hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
+  hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0 ? 1 : 0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
                                                                         s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream, nullptr, nullptr, s->eigen_layout), "eigen launch");
   te.stop();
   count_launch(s, 3);
@@ -1327,6 +1327,9 @@ void set_eigen_chunk(storm_sweep* q, const double* freq, const int* pos, size_t 
   hip_check(hipMemcpyAsync(q->d_freq.p, q->h_in.p, m * sizeof(double), hipMemcpyHostToDevice, q->stream), "freq H2D");
   hip_check(hipMemcpyAsync(q->d_sys.p, hs, m * sizeof(int), hipMemcpyHostToDevice, q->stream), "system index H2D");
   const size_t n_int = q->n_int, len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+  auto eigen = q->arith ? storm_fast::launch_eigen : storm::launch_eigen;
+  // with the lane-per-mode kernels the whole chunk is eliminated in one launch whatever the systems' classes
+  const bool lanes = storm::eigen_uses_lanes(m, q->eigen_layout);
   size_t first = 0;
   for (int c = 0; c < kSetClasses; ++c) {
     size_t last = first;
@@ -1335,14 +1338,22 @@ void set_eigen_chunk(storm_sweep* q, const double* freq, const int* pos, size_t 
     if (n) {
       double* steps = q->d_steps.p + first * n_int * 16;
       hip_check(g_launch_build[q->arith][q->scheme](set_args(q, c, first, n, steps)), "build_steps launch");
-      hip_check((q->arith ? storm_fast::launch_eigen : storm::launch_eigen)(
-                    q->h_table[q->cls_begin[c]], set_class_ell0(c), q->d_freq.p + first, n, steps, q->d_upper.p + first * ustride,
-                    q->d_swaps.p + first * 2, q->d_det.p + first, q->d_vec.p + first * len, q->stream, q->d_table.p,
-                    q->d_sys.p + first, q->eigen_layout),
-                "eigen launch");
-      q->stats.launches += 3;
+      q->stats.launches += 1;
+      if (!lanes) {
+        hip_check(eigen(q->h_table[q->cls_begin[c]], set_class_ell0(c) ? 1 : 0, q->d_freq.p + first, n, steps,
+                        q->d_upper.p + first * ustride, q->d_swaps.p + first * 2, q->d_det.p + first, q->d_vec.p + first * len,
+                        q->stream, q->d_table.p, q->d_sys.p + first, 1),
+                  "eigen launch");
+        q->stats.launches += 2;
+      }
     }
     first = last;
+  }
+  if (lanes) {
+    hip_check(eigen(q->h_table[0], 2, q->d_freq.p, m, q->d_steps.p, q->d_upper.p, q->d_swaps.p, q->d_det.p, q->d_vec.p, q->stream,
+                    q->d_table.p, q->d_sys.p, 2),
+              "eigen launch");
+    q->stats.launches += 2;
   }
   q->stats.eigenvectors += m;
 }
