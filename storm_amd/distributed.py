@@ -71,3 +71,35 @@ def sharded_scan_and_optimize(solver, freqs, ulp, device="cpu"):
     res, _, inv = solver.scan_and_optimize(mine, ulp) if len(mine) else ([], None, False)
     rec, any_inv = gather_brackets(pack(res, lo), inv, device)
     return unpack(rec), any_inv, res
+
+
+# ---- rotation sweeps (storm_sweep): systems are independent, so they are dealt out whole ----
+def shard_systems(n_sys, world, rank):
+    """Indices of the systems rank `rank` runs: contiguous blocks (systems of one rotation rate sit next to each other
+    and share their model interpolation), sizes differing by at most one."""
+    base, extra = divmod(n_sys, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def sharded_sweep_scan(make_sweep, n_sys, freq_grids, scan, device="cpu"):
+    """Runs scan_and_optimize of n_sys systems over the ranks of the default process group and returns, on every rank,
+    the per-system bracket lists of ALL systems (caller order).
+
+    make_sweep(indices) builds this rank's sweep object over the given systems; scan(sweep, grids) returns one bracket
+    list (dicts with lo_x, lo_f, hi_x, hi_f, root, evals) per system.  The only collective is the gather of the
+    results: two all_gathers (counts, padded records), as in gather_brackets."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        mine = list(range(n_sys))
+        return scan(make_sweep(mine), [freq_grids[u] for u in mine]) if n_sys else []
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = shard_systems(n_sys, world, rank)
+    local = scan(make_sweep(mine), [freq_grids[u] for u in mine]) if mine else []
+    rows = [(float(u), b["lo_x"], b["lo_f"], b["hi_x"], b["hi_f"], b["root"], float(b["evals"]))
+            for u, br in zip(mine, local) for b in br]
+    rec = np.array(rows, dtype=np.float64).reshape(len(rows), RECORD)
+    allrec, _ = gather_brackets(rec, False, device)
+    out = [[] for _ in range(n_sys)]
+    for r in allrec:
+        out[int(r[0])].append(dict(lo_x=r[1], lo_f=r[2], hi_x=r[3], hi_f=r[4], root=r[5], evals=int(r[6])))
+    return out

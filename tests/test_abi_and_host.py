@@ -80,6 +80,34 @@ def test_no_cpu_fallback_when_no_gpu():
     assert not h.value
 
 
+def test_sweep_argument_validation_without_gpu():
+    from storm_amd import ffi
+    L = ffi.load_library()
+    h = C.c_void_p()
+    assert L.storm_sweep_create(None, 1, C.byref(h)) == -1
+    d = (ffi.SystemDesc * 2)()
+    assert L.storm_sweep_create(d, 0, C.byref(h)) == -1
+    assert b"at least one" in L.storm_last_error()
+    one = np.ones(2)
+    p = one.ctypes.data_as(C.POINTER(C.c_double))
+    d[0] = ffi.SystemDesc(1, 0, 0, 1, 2, p, p, p, p, p, p, 1.0, 0.0, 3.0)
+    d[1] = ffi.SystemDesc(0, 0, 0, 1, 1, p, p, p, p, p, p, 1.0, 0.0, 3.0)   # another scheme
+    assert L.storm_sweep_create(d, 2, C.byref(h)) == -1
+    assert b"share the scheme" in L.storm_last_error()
+    d[1] = ffi.SystemDesc(1, 2, 0, 2, 2, p, p, p, p, p, p, 1.0, 0.0, 3.0)   # another grid
+    assert L.storm_sweep_create(d, 2, C.byref(h)) == -1
+    L.storm_sweep_destroy(None)  # no-op
+    assert L.storm_sweep_size(None) == 0
+    assert L.storm_sweep_det(None, None, None, None) == -1
+    assert L.storm_sweep_scan_and_optimize(None, None, None, 1, None, 0, None, None, None, None) == -1
+    assert L.storm_sweep_modes(None, None, None, None, None, None, None, None, None, 0) == -1
+    import torch
+    if not torch.cuda.is_available():   # no CPU fallback
+        d[1] = ffi.SystemDesc(1, 2, 0, 1, 2, p, p, p, p, p, p, 1.0, 0.0, 3.0)
+        assert L.storm_sweep_create(d, 2, C.byref(h)) == -2
+        assert not h.value
+
+
 def test_precision_conversion():
     from storm_amd import ffi
     assert ffi.relative_to_ulp(1e-8) == 45035996   # CLI default, reference src/bracket.rs:30-40

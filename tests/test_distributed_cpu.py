@@ -59,3 +59,61 @@ def test_shard_bounds_cover_every_pair_once():
                 assert 0 <= lo <= hi <= n
             if n < 1000:
                 assert pairs == [(i, i + 1) for i in range(max(0, n - 1))]
+
+
+class _OracleSweep:
+    """Test-only stand-in for SolverSweep: the oracle, system by system (what is under test is the dealing and the gather)."""
+
+    def __init__(self, storm_ref, model, systems):
+        grid = model.field("r_coord")
+        self.solvers = [storm_ref.Solver(model, ell, m, "colloc2", grid) for ell, m in systems]
+
+    def scan(self, grids):
+        return [s.scan_and_optimize(g, 1)[0] for s, g in zip(self.solvers, grids)]
+
+
+_SYSTEMS = [(0, 0), (1, 0), (1, 1), (2, 0), (2, -1)]
+
+
+def _sweep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import storm_ref
+    from storm_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = storm_ref.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_zams.npz"))
+        model.set_rotation_constant(0.05)
+        grids = [storm_ref.linspace(1.0 + 0.5 * k, 14.0, 30 + k) for k in range(len(_SYSTEMS))]
+        res = D.sharded_sweep_scan(lambda idx: _OracleSweep(storm_ref, model, [_SYSTEMS[u] for u in idx]), len(_SYSTEMS),
+                                   grids, lambda sw, g: sw.scan(g))
+        np.save(os.path.join(out_dir, f"sweep{rank}.npy"),
+                np.array([[u, b["lo_x"], b["hi_x"], b["root"], b["evals"]] for u, br in enumerate(res) for b in br]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sweep_matches_single_process(tmp_path, oracle, world):
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_sweep_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    model = oracle.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_zams.npz"))
+    model.set_rotation_constant(0.05)
+    grids = [oracle.linspace(1.0 + 0.5 * k, 14.0, 30 + k) for k in range(len(_SYSTEMS))]
+    ref = _OracleSweep(oracle, model, _SYSTEMS).scan(grids)
+    ref_rows = np.array([[u, b["lo_x"], b["hi_x"], b["root"], b["evals"]] for u, br in enumerate(ref) for b in br])
+    assert ref_rows.shape[0] > 5
+    for r in range(world):
+        got = np.load(tmp_path / f"sweep{r}.npy")
+        assert np.array_equal(got.view(np.uint64), ref_rows.view(np.uint64)), f"rank {r}"
+
+
+def test_shard_systems_partition():
+    from storm_amd import distributed as D
+    for n in (0, 1, 5, 8, 64, 1001 * 8):
+        for world in (1, 2, 3, 8):
+            parts = [D.shard_systems(n, world, r) for r in range(world)]
+            assert sum(parts, []) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
