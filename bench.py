@@ -36,7 +36,7 @@ FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "collo
                   "magnus2": 1486.0, "magnus4": 1848.0, "magnus6": 2562.0, "magnus8": 3900.1}
 # HBM bytes per launch of the dominant kernels, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 # (profiles/r01_pmc_det_hex_colloc8.txt; raw counters in KB, no width correction applied).
-TRAFFIC = {"det_hex<colloc8>": 10871.2e3 + 156.25e3}
+TRAFFIC = {"det_hex<colloc8>": 10872.8e3 + 156.25e3}
 PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz); = dense FP64 MFMA peak
 
 # longest jobs first (colloc8 costs ~2x magnus6) so their latency-bound tails overlap the other scans

@@ -18,7 +18,7 @@ def short(name):
     m = re.match(r"(?:void )?storm(_fast)?::(\w+)(?:<([^>]*)>)?\(", name)
     if m:  # demangled
         targs = [a.strip() for a in (m.group(3) or "").split(",") if a.strip()]
-        if targs and targs[0].isdigit():
+        if targs and targs[0].isdigit() and not m.group(2).startswith("eigen"):  # (eigen kernels: an ell class, not a scheme)
             targs[0] = NAMES[int(targs[0])]
         targs = [{"true": "1", "false": "0"}.get(a, a) for a in targs]
         return ("fast:" if m.group(1) else "") + m.group(2) + (f"<{','.join(targs)}>" if targs else "")
@@ -32,7 +32,7 @@ def short(name):
             scheme = targs.group(1)
             flags = re.findall(r"Lb([01])E", targs.group(2))
             names = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magnus6", "magnus8"]
-            parts = ([names[int(scheme)]] if scheme is not None else []) + flags
+            parts = ([scheme if base.startswith("eigen") else names[int(scheme)]] if scheme is not None else []) + flags
             return f"{base}<{','.join(parts)}>"
         return base
     return name[:60]
