@@ -252,13 +252,16 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16/32-lanes-per-frequency fused kernel
  *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default) the one whose wave count packs the
  *                GPU's wave slots better for this batch, 16, or 32
+ *   "eigen_layout": eigenvector kernels: 0 (default) one wave per mode below 1536 modes per launch and one lane per
+ *                   mode from there on, 1 always wave per mode, 2 always lane per mode (same bits either way)
  *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
  *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)
  *   "fused_min_n": batch size from which "path" 0 picks the fused kernel
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 
-/* Counters and options of a sweep ("arithmetic", "hex_lanes", "steps_bytes_max" as below). */
+/* Counters and options of a sweep ("arithmetic", "hex_lanes", "eigen_layout", "steps_bytes_max" as below; the
+ * staging cap defaults to 16 GiB for a sweep). */
 int storm_sweep_stats(storm_sweep* sweep, storm_stats* out, int reset);
 int storm_sweep_set_option(storm_sweep* sweep, const char* key, int64_t value);
 
