@@ -270,3 +270,44 @@ def test_lane_per_mode_tiny_grids_and_sweep(oracle):
             rdet, rvec = o.eigenvector(f[k], threads=4)
             assert same_bits(got[k][1], rvec), (npts, k)
             assert same_bits(got[k][0], rdet), (npts, k)
+
+
+def test_full_size_configs_4_and_5_as_one_sweep(oracle, golden_dir):
+    """BASELINE configs 4 and 5 (tams, rot = 0.1, Colloc4, 10^4 frequencies per scan; config 5 on the period-linear
+    grid) as ONE sweep of nine systems, eigenvectors of all ~190 modes with both kernel layouts.  Checked against one
+    storm_solver per system (every bit of every result) and against the oracle on a sample."""
+    import storm_amd
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_tams.npz"))
+    model.set_rotation_constant(0.1)
+    grid = model.field("r_coord")
+    lin, inv = oracle.linspace(1.0, 25.0, 10000), oracle.rev_linspace(0.5, 1.0, 10000)
+    cfg = [(1, -1, lin), (1, 1, lin), (2, -1, lin), (2, 1, lin), (3, -1, lin), (3, 1, lin), (0, 0, inv), (2, 0, inv), (4, 0, inv)]
+    solvers = [oracle.Solver(model, ell, m, "colloc4", grid) for ell, m, _ in cfg]
+    grids = [g for _, _, g in cfg]
+    ulp = oracle.relative_to_ulp(1e-8)
+    sweep = sweep_from_oracle(solvers)
+    got = sweep.scan_and_optimize(grids, ulp)
+    roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+    n_modes = sum(r.size for r in roots)
+    assert n_modes >= 150, n_modes
+    vecs = sweep.eigenvector(roots)          # wave per mode at this count
+    sweep.set_option("eigen_layout", 2)
+    lane_vecs = sweep.eigenvector(roots)     # what a launch of >= 1536 modes takes
+    for a, b in zip(vecs, lane_vecs):
+        assert same_bits(a[0], b[0]) and same_bits(a[1], b[1])
+    rng = np.random.default_rng(17)
+    for k, o in enumerate(solvers):
+        h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+        ref, rdets, rinv = h.scan_and_optimize(grids[k], ulp)
+        assert same_bits(got[k][1], rdets) and got[k][2] == rinv, k
+        assert same_brackets(ref, got[k][0]), k
+        if roots[k].size:
+            rdet, rvec = h.eigenvector(roots[k])
+            assert same_bits(vecs[k][1], rvec) and same_bits(vecs[k][0], rdet), k
+            sel = rng.choice(roots[k].size, min(3, roots[k].size), replace=False)
+            odet, ovec = o.eigenvector(roots[k][sel], threads=16)
+            assert same_bits(vecs[k][1][sel], ovec) and same_bits(vecs[k][0][sel], odet), k
+        idx = np.unique(np.concatenate([rng.choice(10000, 128, replace=False),
+                                        np.array([b["index"] for b in got[k][0]], dtype=np.int64)])).astype(np.int64)
+        assert same_bits(o.det(grids[k][idx], threads=16), got[k][1][idx]), k
+    assert got[6][0] == []                   # no radial mode below the fundamental
