@@ -251,7 +251,9 @@ def main():
     NOTE_PARITY = ("algorithmic un-fused flops (oracle op count x evals per launch) / HIP-event duration of the kernel "
                    "run alone; parity arithmetic = the reference's separate mul and add (bit-exact results), whose "
                    "measured chip-wide issue ceiling is 38.1 TFLOP/s (tools/fp64_microbench.hip) = 0.485 of the "
-                   "FMA-counted peak; traffic = HBM bytes per launch from rocprofv3 PMC passes (profiles/)")
+                   "FMA-counted peak (78.6 TFLOP/s vector FP64 = the dense FP64 MFMA figure of MI355X_MICROARCH.md; the path is "
+                   "4x4 products in a strict order, priced against the vector pipe, not reshaped for MFMA); traffic = HBM "
+                   "bytes per launch from rocprofv3 PMC passes (profiles/)")
     NOTE_FAST = ("same kernel built with FMA contraction (option arithmetic=1): results agree with the reference to "
                  "rounding (tests/test_hip_fast_mode.py: identical bracket indices, roots within 1e-10); algorithmic "
                  "flops are still the reference's un-fused count")
