@@ -216,6 +216,20 @@ int storm_sweep_modes(storm_sweep* sweep, storm_postproc* const* posts, const si
                       double* det_out, double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out,
                       size_t node_cap);
 
+/* post-process followed by perturb-deformed (src/main.rs:878-940) without the fields leaving HBM.
+ * storm_sweep_modes_resident = storm_sweep_modes that returns ids (and nodes) only and keeps the 13 post-processing
+ * fields of every mode of the call on the device (they must fit the staging cap in one pass, else
+ * STORM_ERR_CAPACITY); a later storm_sweep_modes* call replaces them.
+ * storm_sweep_coupling_matrices = storm_coupling_matrices on n of those modes: mode_index[k] is the position of
+ * mode k in the freq array of the resident call (the modes of one `output` block with sol.m == m, in scan order,
+ * src/main.rs:922-934); ell[k], freq[k], metric and out as in storm_coupling_matrices; post = the model the
+ * integrals run on (the input evaluated on the grid when perturb-deformed runs). */
+int storm_sweep_modes_resident(storm_sweep* sweep, storm_postproc* const* posts, const size_t* offsets,
+                               const double* freq, storm_mode_id* ids_out, double* nodes_out, size_t node_cap);
+int storm_sweep_coupling_matrices(storm_sweep* sweep, storm_postproc* post, size_t n, const size_t* mode_index,
+                                  const uint64_t* ell, const double* freq, int64_t m,
+                                  const storm_metric_desc* metric, double* out);
+
 /* ---- Memory cache (no counterpart in the reference) ----
  * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
  * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent

@@ -475,6 +475,45 @@ std::vector<std::vector<double>> SolverSweep::eigenvectors(const std::vector<std
 std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes(const std::vector<const PostProcessor*>& posts,
                                                                       const std::vector<std::vector<double>>& roots,
                                                                       bool want_fields) const {
+  return run_modes(posts, roots, want_fields, false);
+}
+std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes_resident(const std::vector<const PostProcessor*>& posts,
+                                                                               const std::vector<std::vector<double>>& roots) const {
+  return run_modes(posts, roots, false, true);
+}
+
+CouplingMatrices SolverSweep::coupling_matrices(const PostProcessor& post, const std::vector<ModeRef>& modes, int64_t m,
+                                                const PerturbedMetric& metric) const {
+  const size_t n = modes.size(), np = n_int_ + 1;
+  if (resident_off_.empty()) throw std::runtime_error("SolverSweep::coupling_matrices: call modes_resident first");
+  for (const std::vector<double>* v : {&metric.alpha, &metric.dalpha, &metric.ddalpha, &metric.beta, &metric.dbeta, &metric.ddbeta})
+    if (v->size() != np) throw std::runtime_error("coupling_matrices: metric arrays must have the model's length");
+  std::vector<size_t> index(n);
+  std::vector<uint64_t> ell(n);
+  std::vector<double> freq(n);
+  for (size_t k = 0; k < n; ++k) {
+    const ModeRef& r = modes[k];
+    if (r.system >= size() || resident_off_[r.system] + r.mode >= resident_off_[r.system + 1])
+      throw std::runtime_error("coupling_matrices: no such resident mode");
+    index[k] = resident_off_[r.system] + r.mode;
+    ell[k] = ell_[r.system];
+    freq[k] = resident_freq_[index[k]];
+  }
+  storm_metric_desc md{metric.alpha.data(), metric.dalpha.data(), metric.ddalpha.data(),
+                       metric.beta.data(), metric.dbeta.data(), metric.ddbeta.data()};
+  std::vector<double> out(size_t(STORM_COUPLING_MATRICES) * n * n);
+  const int rc = storm_sweep_coupling_matrices(h_, post.handle(), n, index.data(), ell.data(), freq.data(), m, &md, out.data());
+  if (rc != STORM_OK) raise_abi("storm_sweep_coupling_matrices", rc);
+  CouplingMatrices c;
+  c.n = n;
+  std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
+  for (int q = 0; q < STORM_COUPLING_MATRICES; ++q) dst[q]->assign(out.begin() + size_t(q) * n * n, out.begin() + size_t(q + 1) * n * n);
+  return c;
+}
+
+std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::run_modes(const std::vector<const PostProcessor*>& posts,
+                                                                          const std::vector<std::vector<double>>& roots,
+                                                                          bool want_fields, bool resident) const {
   if (posts.size() != size()) throw std::runtime_error("SolverSweep::modes: one PostProcessor per system expected");
   std::vector<double> flat;
   const std::vector<size_t> off = flatten(roots, size(), flat);
@@ -489,13 +528,16 @@ std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::modes(const std:
   size_t cap = std::min(np, size_t(256));  // see kNodeCapFirst
   for (;; cap = np) {
     nodes.resize(n * cap);
-    const int rc = storm_sweep_modes(h_, handles.data(), off.data(), flat.data(), nullptr, nullptr,
-                                     want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), cap);
-    if (rc != STORM_OK) raise_abi("storm_sweep_modes", rc);
+    const int rc = resident ? storm_sweep_modes_resident(h_, handles.data(), off.data(), flat.data(), ids.data(), nodes.data(), cap)
+                            : storm_sweep_modes(h_, handles.data(), off.data(), flat.data(), nullptr, nullptr,
+                                                want_fields ? fields.data() : nullptr, ids.data(), nodes.data(), cap);
+    if (rc != STORM_OK) raise_abi(resident ? "storm_sweep_modes_resident" : "storm_sweep_modes", rc);
     bool fits = true;
     for (size_t k = 0; k < n; ++k) fits = fits && ids[k].n_nodes <= cap;
     if (fits || cap == np) break;
   }
+  resident_off_.clear(); resident_freq_.clear();
+  if (resident) { resident_off_ = off; resident_freq_ = flat; }
   std::vector<std::vector<Rotating1DPostprocessing>> res(size());
   for (size_t u = 0; u < size(); ++u) {
     const size_t a = off[u], cnt = off[u + 1] - off[u];

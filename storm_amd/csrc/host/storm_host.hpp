@@ -240,15 +240,28 @@ class SolverSweep {
   std::vector<std::vector<Rotating1DPostprocessing>> modes(const std::vector<const PostProcessor*>& posts,
                                                            const std::vector<std::vector<double>>& roots,
                                                            bool want_fields) const;
+  // post-process + perturb-deformed with the fields staying on the device: modes_resident returns ids and nodes only
+  // (the per-point arrays of the results are empty) and keeps the fields of all modes of the call in HBM;
+  // coupling_matrices then integrates a subset of them: mode (u, k) = mode k of system u of that call.
+  std::vector<std::vector<Rotating1DPostprocessing>> modes_resident(const std::vector<const PostProcessor*>& posts,
+                                                                    const std::vector<std::vector<double>>& roots) const;
+  struct ModeRef { size_t system, mode; };
+  CouplingMatrices coupling_matrices(const PostProcessor& model_on_grid, const std::vector<ModeRef>& modes, int64_t m,
+                                     const PerturbedMetric& metric) const;
   size_t size() const { return ell_.size(); }
   size_t len() const { return n_int_; }
   storm_sweep* handle() const { return h_; }
 
  private:
+  std::vector<std::vector<Rotating1DPostprocessing>> run_modes(const std::vector<const PostProcessor*>& posts,
+                                                               const std::vector<std::vector<double>>& roots,
+                                                               bool want_fields, bool resident) const;
   storm_sweep* h_ = nullptr;
   size_t n_int_ = 0;
   std::vector<uint64_t> ell_;
   std::vector<int64_t> m_;
+  mutable std::vector<size_t> resident_off_;               // offsets of the resident call
+  mutable std::vector<double> resident_freq_;
 };
 
 }  // namespace storm_host

@@ -12,6 +12,8 @@
 //   post_fields   lane = (mode, point): all 13 fields recomputed and stored scaled          (136 B/pt/mode)
 // Recomputing the point in post_fields costs ~80 flops and saves storing + re-reading 13 unscaled fields.
 #include "postprocess.hpp"
+
+#include <algorithm>
 #include "shared_div.hpp"
 
 #define PDEV __device__ __forceinline__
@@ -378,6 +380,25 @@ hipError_t launch_postprocess(const PostArgs& a) {
     e = hipGetLastError();
   }
   return e;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ src, const long long* __restrict__ index,
+                                                          size_t row_elems, double* __restrict__ dst) {
+  const size_t k = blockIdx.y;
+  const double* __restrict__ from = src + (size_t)index[k] * row_elems;
+  double* __restrict__ to = dst + k * row_elems;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < row_elems; e += (size_t)gridDim.x * 256) to[e] = from[e];
+}
+}  // namespace
+
+hipError_t launch_gather_rows(const double* src, const long long* index, size_t n, size_t row_elems, double* dst,
+                              hipStream_t stream) {
+  if (n == 0 || row_elems == 0) return hipSuccess;
+  if (n > 65535) return hipErrorInvalidValue;
+  const unsigned bx = (unsigned)std::min<size_t>((row_elems + 255) / 256, 128);
+  gather_rows_kernel<<<dim3(bx, (unsigned)n, 1), 256, 0, stream>>>(src, index, row_elems, dst);
+  return hipGetLastError();
 }
 
 hipError_t launch_coupling(const CouplingArgs& a) {

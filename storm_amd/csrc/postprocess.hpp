@@ -95,4 +95,9 @@ struct CouplingArgs {
 };
 hipError_t launch_coupling(const CouplingArgs& args);
 
+// dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
+// a subset of modes out of a larger resident set without leaving HBM.
+hipError_t launch_gather_rows(const double* src, const long long* index, size_t n, size_t row_elems, double* dst,
+                              hipStream_t stream);
+
 }  // namespace storm

@@ -247,6 +247,8 @@ struct storm_postproc {
   DevBuf<long long> d_ids;
   DevBuf<double> d_weights, d_consts, d_out;  // coupling integrals
   DevBuf<int> d_ell_index, d_cflags;
+  DevBuf<long long> d_gather;                 // rows to pick out of a sweep's resident fields
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the coupling kernel
   std::vector<double> h_r, h_rho, h_rot, h_trap;  // host copies of the planes the coupling weights are built from
   PinnedBuf h_stage;
   std::vector<long long> h_ids;
@@ -957,11 +959,13 @@ void storm_postproc_destroy(storm_postproc* p) {
   (void)hipSetDevice(p->device);
   if (p->ready) { (void)hipEventSynchronize(p->ready); (void)hipEventDestroy(p->ready); }
   if (p->sync_marker) (void)hipEventDestroy(p->sync_marker);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream) { (void)hipStreamSynchronize(p->stream); MemoryCache::get().give_stream(p->device, p->stream); }
   p->h_model.release();
   p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
   p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
-  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release();
+  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release(); p->d_gather.release();
   (void)hipSetDevice(prev);
   delete p;
 }
@@ -991,10 +995,16 @@ int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const do
   });
 }
 
-int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, const double* freq, const double* fields,
-                            int64_t m, const storm_metric_desc* metric, double* out) {
-  return guarded([&] {
-    if (!p || (n && (!ell || !freq || !fields || !metric || !out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+}  // extern "C"
+
+namespace {
+// The coupling integrals of n modes whose 13 fields `provide_fields` puts into p->d_fields ([n][13][n_pts]) on the
+// given stream: an upload of host arrays (storm_coupling_matrices) or a device-side gather of fields that never left
+// HBM (storm_sweep_coupling_matrices).  Caller holds no lock; arguments are validated here.
+template <class ProvideFields>
+void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double* freq, int64_t m,
+                  const storm_metric_desc* metric, double* out, ProvideFields&& provide_fields) {
+    if (!p || (n && (!ell || !freq || !metric || !out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return;
     const double* ms[6] = {metric->alpha, metric->dalpha, metric->ddalpha, metric->beta, metric->dbeta, metric->ddbeta};
     for (const double* q : ms)
@@ -1067,7 +1077,7 @@ int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, co
     p->d_out.reserve(size_t(kCouplingMatrices) * n * n, p->stream);
     p->d_cflags.reserve(1, p->stream);
     hipStream_t st = post_stream(p);
-    hip_check(hipMemcpyAsync(p->d_fields.p, fields, nf * sizeof(double), hipMemcpyHostToDevice, st), "fields H2D");
+    provide_fields(p->d_fields.p, st);
     hip_check(hipMemcpyAsync(p->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
     hip_check(hipMemcpyAsync(p->d_weights.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st), "weights H2D");
     hip_check(hipMemcpyAsync(p->d_consts.p, consts.data(), consts.size() * sizeof(double), hipMemcpyHostToDevice, st), "consts H2D");
@@ -1077,21 +1087,40 @@ int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, co
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
     a.stream = st;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hip_check(hipEventCreate(&e0), "hipEventCreate");
-    hip_check(hipEventCreate(&e1), "hipEventCreate");
-    hip_check(hipEventRecord(e0, st), "hipEventRecord");
+    if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
+    if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
+    hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
     hip_check(launch_coupling(a), "coupling launch");
-    hip_check(hipEventRecord(e1, st), "hipEventRecord");
-    int flags = 0;
-    hip_check(hipMemcpyAsync(out, p->d_out.p, size_t(kCouplingMatrices) * n * n * sizeof(double), hipMemcpyDeviceToHost, st), "out D2H");
-    hip_check(hipMemcpyAsync(&flags, p->d_cflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+    hip_check(hipEventRecord(p->ev1, st), "hipEventRecord");
+    // results through pinned memory (a copy to pageable memory takes the runtime's staged, host-synchronous path)
+    const size_t n_out = size_t(kCouplingMatrices) * n * n;
+    p->h_stage.reserve(n_out + 1);
+    int* flags_ptr = reinterpret_cast<int*>(p->h_stage.p + n_out);
+    hip_check(hipMemcpyAsync(p->h_stage.p, p->d_out.p, n_out * sizeof(double), hipMemcpyDeviceToHost, st), "out D2H");
+    hip_check(hipMemcpyAsync(flags_ptr, p->d_cflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
     sync_stream(st, p->sync_marker);
+    std::memcpy(out, p->h_stage.p, n_out * sizeof(double));
+    const int flags = *flags_ptr;
     float kernel_ms = 0.f;
-    (void)hipEventElapsedTime(&kernel_ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&kernel_ms, p->ev0, p->ev1);
     p->last_coupling_ms = double(kernel_ms);
+    // The mode fields are by far the largest buffer of the handle (n x 13 x n_pts) and a rotation sweep has one handle
+    // per rotation rate: hand the block back to the cache so the next handle's call reuses it instead of allocating.
+    p->d_fields.release();
     if (flags & 1) fail(STORM_ERR_NON_FINITE, "Not finite number in a coupling integral (the reference asserts, src/perturbed.rs:165-260)");
+}
+}  // namespace
+
+extern "C" {
+
+int storm_coupling_matrices(storm_postproc* p, size_t n, const uint64_t* ell, const double* freq, const double* fields,
+                            int64_t m, const storm_metric_desc* metric, double* out) {
+  return guarded([&] {
+    if (n && !fields) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    coupling_run(p, n, ell, freq, m, metric, out, [&](double* d_fields, hipStream_t st) {
+      hip_check(hipMemcpyAsync(d_fields, fields, n * kPostFields * p->model.n_pts * sizeof(double), hipMemcpyHostToDevice, st),
+                "fields H2D");
+    });
   });
 }
 
@@ -1179,6 +1208,9 @@ struct storm_sweep {
   DevBuf<double> d_terms, d_scale, d_fields, d_nodes;  // post-processing scratch (storm_sweep_modes)
   DevBuf<long long> d_ids;
   DevBuf<PostSystem> d_post_table;                     // (model, ell, m) of every system, internal order
+  // storm_sweep_modes_resident: the 13 fields of every mode of that call stay in d_fields (internal order);
+  // resident_at[i] = row of the mode the caller passed i-th.  Any other modes call drops them.
+  std::vector<long long> resident_at;
   PinnedBuf h_in, h_out, h_flags;
   int arith = 0, hex_lanes = 0, eigen_layout = 0;
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
@@ -1604,9 +1636,9 @@ int storm_sweep_scan_and_optimize(storm_sweep* q, const size_t* freq_offsets, co
   });
 }
 
-int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t* offsets, const double* freq,
-                                 double* det_out, double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out,
-                                 size_t node_cap) {
+static int sweep_modes_impl(storm_sweep* q, storm_postproc* const* posts, const size_t* offsets, const double* freq,
+                            double* det_out, double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out,
+                            size_t node_cap, bool resident) {
   return guarded([&] {
     if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
     set_validate_offsets(q, offsets);
@@ -1634,8 +1666,10 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
     set_mode_order(q, offsets, src, pos);
     std::vector<double> fr(n);
     for (size_t j = 0; j < n; ++j) fr[j] = freq[src[j]];
-    const bool want_fields = fields_out != nullptr;
+    const bool want_fields = fields_out != nullptr || resident;
     const size_t ncap = nodes_out ? node_cap : 0;
+    q->resident_at.clear();  // d_fields is about to be reused
+    if (resident && !post) fail(STORM_ERR_INVALID_ARGUMENT, "resident fields need the post-processing handles");
     size_t chunk = set_eigen_reserve(q, n);
     if (post) {
       const size_t per_mode = (np * (1 + (want_fields ? kPostFields : 0)) + ncap + 8) * sizeof(double);
@@ -1645,6 +1679,8 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
       q->d_ids.reserve(chunk * 4, q->stream);
       if (want_fields) q->d_fields.reserve(chunk * kPostFields * np, q->stream);
       if (ncap) q->d_nodes.reserve(chunk * ncap, q->stream);
+      if (resident && chunk < n)
+        fail(STORM_ERR_CAPACITY, "the fields of all modes do not fit the staging cap in one pass: raise steps_bytes_max or pass fewer modes");
     }
     std::vector<PostSystem> table;  // outlives the copy below (the stream is synchronised before this call returns)
     if (post) {
@@ -1684,7 +1720,7 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
         q->stats.launches += want_fields ? 3 : 2;
       }
       // results to the host: staged in pinned memory in internal order, scattered to the caller's order
-      const size_t nv = vec_out ? k * len : 0, nf = want_fields ? k * kPostFields * np : 0, nn = ncap ? k * ncap : 0;
+      const size_t nv = vec_out ? k * len : 0, nf = fields_out ? k * kPostFields * np : 0, nn = ncap ? k * ncap : 0;
       q->h_out.reserve(nv + nf + nn + k + 1);
       double* hv = q->h_out.p; double* hf = hv + nv; double* hn = hf + nf; double* hd = hn + nn;
       if (nv) hip_check(hipMemcpyAsync(hv, q->d_vec.p, nv * sizeof(double), hipMemcpyDeviceToHost, q->stream), "vec D2H");
@@ -1699,7 +1735,7 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
       for (size_t j = 0; j < k; ++j) {
         const size_t dst = src[off + j];
         if (vec_out) std::memcpy(vec_out + dst * len, hv + j * len, len * sizeof(double));
-        if (want_fields) std::memcpy(fields_out + dst * kPostFields * np, hf + j * kPostFields * np, kPostFields * np * sizeof(double));
+        if (fields_out) std::memcpy(fields_out + dst * kPostFields * np, hf + j * kPostFields * np, kPostFields * np * sizeof(double));
         if (ncap) std::memcpy(nodes_out + dst * ncap, hn + j * ncap, ncap * sizeof(double));
         if (det_out) det_out[dst] = hd[j];
         if (post)
@@ -1707,6 +1743,52 @@ int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t
                                        uint64_t(h_ids[j * 4 + 3])};
       }
     }
+    if (resident) {
+      q->resident_at.assign(n, 0);
+      for (size_t j = 0; j < n; ++j) q->resident_at[src[j]] = (long long)j;
+    }
+  });
+}
+
+int storm_sweep_modes(storm_sweep* q, storm_postproc* const* posts, const size_t* offsets, const double* freq, double* det_out,
+                      double* vec_out, double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {
+  return sweep_modes_impl(q, posts, offsets, freq, det_out, vec_out, fields_out, ids_out, nodes_out, node_cap, false);
+}
+
+int storm_sweep_modes_resident(storm_sweep* q, storm_postproc* const* posts, const size_t* offsets, const double* freq,
+                               storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {
+  return sweep_modes_impl(q, posts, offsets, freq, nullptr, nullptr, nullptr, ids_out, nodes_out, node_cap, true);
+}
+
+int storm_sweep_coupling_matrices(storm_sweep* q, storm_postproc* p, size_t n, const size_t* mode_index, const uint64_t* ell,
+                                  const double* freq, int64_t m, const storm_metric_desc* metric, double* out) {
+  return guarded([&] {
+    if (!q || !p || (n && !mode_index)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    if (q->device != p->device) fail(STORM_ERR_INVALID_ARGUMENT, "sweep and post-processing handle live on different devices");
+    if (p->model.n_pts != q->n_int + 1)
+      fail(STORM_ERR_INVALID_ARGUMENT, "the solver grid is not the post-processing model's grid (n_int + 1 != n_pts)");
+    std::vector<long long> rows(n);
+    const double* resident_fields = nullptr;
+    {
+      // Only the row lookup is under the sweep's lock: integrals of different blocks may run concurrently from several
+      // host threads (each on its own post-processing handle and stream).  The caller must not start another
+      // storm_sweep_modes* call on this sweep while they run (it would overwrite the resident fields).
+      std::lock_guard<std::mutex> lock(q->mu);
+      if (q->resident_at.empty()) fail(STORM_ERR_INVALID_ARGUMENT, "no resident fields: call storm_sweep_modes_resident first");
+      for (size_t k = 0; k < n; ++k) {
+        if (mode_index[k] >= q->resident_at.size()) fail(STORM_ERR_INVALID_ARGUMENT, "mode index out of range");
+        rows[k] = q->resident_at[mode_index[k]];
+      }
+      resident_fields = q->d_fields.p;
+    }
+    const size_t row_elems = size_t(kPostFields) * (q->n_int + 1);
+    coupling_run(p, n, ell, freq, m, metric, out, [&](double* d_fields, hipStream_t st) {
+      // the resident fields were completed by a call that synchronised the sweep's stream: safe to read from `st`
+      p->d_gather.reserve(n, st);
+      hip_check(hipMemcpyAsync(p->d_gather.p, rows.data(), n * sizeof(long long), hipMemcpyHostToDevice, st), "gather index H2D");
+      hip_check(launch_gather_rows(resident_fields, p->d_gather.p, n, row_elems, d_fields, st), "gather launch");
+    });
   });
 }
 

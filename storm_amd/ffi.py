@@ -64,7 +64,7 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats",
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
            "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
-           "storm_sweep_set_option"]
+           "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices"]
 
 _lib = None
 
@@ -124,6 +124,9 @@ def load_library():
     L.storm_sweep_eigenvectors.argtypes = [C.c_void_p, _sp, _dp, _dp, _dp]
     L.storm_sweep_modes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _sp, _dp, _dp, _dp, _dp, C.POINTER(ModeId), _dp,
                                     C.c_size_t]
+    L.storm_sweep_modes_resident.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _sp, _dp, C.POINTER(ModeId), _dp, C.c_size_t]
+    L.storm_sweep_coupling_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _sp, C.POINTER(C.c_uint64), _dp, C.c_int64,
+                                                C.POINTER(MetricDesc), _dp]
     L.storm_sweep_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
     L.storm_sweep_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _lib = L

@@ -17,7 +17,10 @@
 // record (hex floats, exact) instead of HDF5; the generalised eigenproblem after the integrals (linalg/qz.rs) is the
 // caller's.
 //
-// usage: storm_batch model.bin batch.txt out.txt [--group N]     (N = blocks executed together, default 16)
+// usage: storm_batch model.bin batch.txt out.txt [--group N] [--threads T] [--summary]
+//        N = blocks executed together (default 16), T = host threads for the per-block integrals (default 8),
+//        --summary writes one checksum per coupling matrix instead of its entries (timing runs)
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,8 +28,10 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../storm_amd/csrc/host/storm_host.hpp"
@@ -135,9 +140,15 @@ void put(FILE* f, double v) { std::fprintf(f, " %a", v); }
 
 int main(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
-  size_t group = 16;
-  for (int k = 4; k + 1 < argc; ++k) if (!std::strcmp(argv[k], "--group")) group = std::strtoul(argv[k + 1], nullptr, 10);
+  size_t group = 16, threads = 8;
+  bool summary = false;  // --summary: one checksum per matrix instead of its n*n entries (for timing runs)
+  for (int k = 4; k < argc; ++k) {
+    if (!std::strcmp(argv[k], "--group") && k + 1 < argc) group = std::strtoul(argv[++k], nullptr, 10);
+    else if (!std::strcmp(argv[k], "--threads") && k + 1 < argc) threads = std::strtoul(argv[++k], nullptr, 10);
+    else if (!std::strcmp(argv[k], "--summary")) summary = true;
+  }
   if (group == 0) group = 1;
+  if (threads == 0) threads = 1;
   FILE* mf = std::fopen(argv[1], "rb");
   if (!mf) { std::perror(argv[1]); return 2; }
   uint64_t n = 0; double rs = 0, msx = 0;
@@ -154,7 +165,7 @@ int main(int argc, char** argv) {
   if (!out) { std::perror(argv[3]); return 2; }
 
   const auto t_all = Clock::now();
-  double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0;
+  double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0, t_write = 0;
   size_t n_scans = 0, n_modes = 0;
   for (size_t g0 = 0; g0 < blocks.size(); g0 += group) {
     const size_t g1 = std::min(blocks.size(), g0 + group);
@@ -186,6 +197,16 @@ int main(int argc, char** argv) {
     std::vector<std::vector<std::vector<BracketResult>>> found(g1 - g0);
     std::vector<std::vector<std::vector<Rotating1DPostprocessing>>> post(g1 - g0);
     for (size_t b = g0; b < g1; ++b) { found[b - g0].resize(blocks[b].scans.size()); post[b - g0].resize(blocks[b].scans.size()); }
+    // If every scan of the group shares scheme and precision (the generator's case) there is ONE sweep, and the 13
+    // fields of its modes stay in HBM between post-processing and the coupling integrals; otherwise they travel
+    // through the host like in the reference.
+    bool one_sweep = by_scheme.size() == 1;
+    if (one_sweep) {
+      const double p0 = blocks[by_scheme.begin()->second[0].block].scans[by_scheme.begin()->second[0].scan].precision;
+      for (const Ref& r : by_scheme.begin()->second) one_sweep = one_sweep && blocks[r.block].scans[r.scan].precision == p0;
+    }
+    std::unique_ptr<SolverSweep> resident;                         // alive until the group's integrals are done
+    std::vector<std::vector<size_t>> system_of(g1 - g0);           // (block, scan) -> system of `resident`
     for (auto& kv : by_scheme) {
       const std::vector<Ref>& refs = kv.second;
       // Precision is one per sweep call: scans are sub-grouped by it (normally a single value)
@@ -201,7 +222,8 @@ int main(int argc, char** argv) {
           systems.push_back(SweepSystem{model_of(s.rot), Rotating1D::make(s.ell, s.m)});
           grids.push_back(s.inverse ? rev_linspace(s.lower, s.upper, s.steps) : linspace(s.lower, s.upper, s.steps));
         }
-        SolverSweep sweep(systems, DifferenceSchemes(kv.first), grid);
+        auto sweep_ptr = std::make_unique<SolverSweep>(systems, DifferenceSchemes(kv.first), grid);
+        SolverSweep& sweep = *sweep_ptr;
         const auto res = sweep.scan_and_optimize(grids, Precision::Relative(pv.first));
         t_scan += ms_since(t); t = Clock::now();
         std::vector<std::vector<double>> roots(rs2.size());
@@ -218,12 +240,75 @@ int main(int argc, char** argv) {
         }
         n_scans += rs2.size();
         // the eigenvector of every mode + its post-processing; the 13 fields only if some block integrates them
-        const auto pr = sweep.modes(posts, roots, fields);
+        const bool keep = fields && one_sweep;
+        const auto pr = keep ? sweep.modes_resident(posts, roots) : sweep.modes(posts, roots, fields);
         for (size_t k = 0; k < rs2.size(); ++k) post[rs2[k].block - g0][rs2[k].scan] = pr[k];
+        if (keep) {
+          for (size_t b = g0; b < g1; ++b) system_of[b - g0].assign(blocks[b].scans.size(), 0);
+          for (size_t k = 0; k < rs2.size(); ++k) system_of[rs2[k].block - g0][rs2[k].scan] = k;
+          resident = std::move(sweep_ptr);
+        }
         t_modes += ms_since(t);
       }
     }
-    // ---- per block: deformation (host) + coupling integrals (device), then the record ----
+    // ---- per block: deformation (host) + coupling integrals (device); blocks are independent, so a few host threads
+    // each take blocks (every rotation rate has its own post-processing handle and stream) ----
+    struct Task { size_t block, which; CouplingMatrices c; size_t n = 0; };
+    std::vector<Task> tasks;
+    for (size_t b = g0; b < g1; ++b)
+      for (size_t w = 0; w < blocks[b].perturb.size(); ++w) {
+        Task tk; tk.block = b; tk.which = w;
+        tasks.push_back(std::move(tk));
+        model_of(blocks[b].metric_model_rot);      // (the maps are filled here, on one thread)
+        post_of(blocks[b].perturb[w].second);
+      }
+    {
+      auto t = Clock::now();
+      std::atomic<size_t> next{0};
+      std::atomic<long long> deform_us{0};
+      std::string error;
+      std::mutex error_mu;
+      auto work = [&] {
+        for (size_t at; (at = next.fetch_add(1)) < tasks.size();) {
+          try {
+            Task& tk = tasks[at];
+            const Block& blk = blocks[tk.block];
+            const auto& pm = blk.perturb[tk.which];
+            const size_t b = tk.block;
+            auto t0 = Clock::now();
+            // deform: perturb_structure on the model as it was at `deform` (main.rs:840-876)
+            const PerturbedMetric metric = perturb_structure(*models.at(blk.metric_model_rot), blk.metric_rot);
+            deform_us += (long long)(ms_since(t0) * 1e3);
+            std::vector<ModeToPerturb> modes;
+            std::vector<SolverSweep::ModeRef> refs;
+            for (size_t s = 0; s < blk.scans.size(); ++s)
+              if (blk.scans[s].m == pm.first)
+                for (size_t k = 0; k < found[b - g0][s].size(); ++k) {
+                  modes.push_back(ModeToPerturb{blk.scans[s].ell, found[b - g0][s][k].root, &post[b - g0][s][k]});
+                  if (resident) refs.push_back({system_of[b - g0][s], k});
+                }
+            tk.n = modes.size();
+            if (!modes.empty())
+              tk.c = resident ? resident->coupling_matrices(*pps.at(pm.second), refs, pm.first, metric)
+                              : pps.at(pm.second)->coupling_matrices(modes, pm.first, metric);
+          } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lock(error_mu);
+            if (error.empty()) error = e.what();
+          }
+        }
+      };
+      const size_t n_thr = std::min<size_t>(tasks.size(), threads);
+      std::vector<std::thread> pool;
+      for (size_t k = 1; k < n_thr; ++k) pool.emplace_back(work);
+      work();
+      for (auto& th : pool) th.join();
+      if (!error.empty()) { std::fprintf(stderr, "storm_batch: %s\n", error.c_str()); return 1; }
+      t_deform += double(deform_us.load()) * 1e-3 / double(std::max<size_t>(1, n_thr));
+      t_couple += ms_since(t);
+    }
+    // ---- the records ----
+    auto t_w = Clock::now();
+    size_t task_at = 0;
     for (size_t b = g0; b < g1; ++b) {
       const Block& blk = blocks[b];
       std::fprintf(out, "block %zu %s scans %zu\n", b, blk.label.c_str(), blk.scans.size());
@@ -238,36 +323,29 @@ int main(int argc, char** argv) {
                        (unsigned long long)p.cross_counter_clockwise, (long long)p.radial_order, p.nodes.size());
         }
       }
-      for (const auto& pm : blk.perturb) {
-        auto t = Clock::now();
-        // deform: perturb_structure on the model as it was at `deform` (main.rs:840-876)
-        model_of(blk.metric_model_rot);
-        const PerturbedMetric metric = perturb_structure(*models[blk.metric_model_rot], blk.metric_rot);
-        t_deform += ms_since(t); t = Clock::now();
-        std::vector<ModeToPerturb> modes;
-        for (size_t s = 0; s < blk.scans.size(); ++s)
-          if (blk.scans[s].m == pm.first)
-            for (size_t k = 0; k < found[b - g0][s].size(); ++k)
-              modes.push_back(ModeToPerturb{blk.scans[s].ell, found[b - g0][s][k].root, &post[b - g0][s][k]});
-        std::fprintf(out, "coupling %lld n %zu\n", (long long)pm.first, modes.size());
-        if (!modes.empty()) {
-          const CouplingMatrices c = post_of(pm.second)->coupling_matrices(modes, pm.first, metric);
+      for (size_t w = 0; w < blk.perturb.size(); ++w, ++task_at) {
+        const Task& tk = tasks[task_at];
+        std::fprintf(out, "coupling %lld n %zu\n", (long long)blk.perturb[w].first, tk.n);
+        if (tk.n) {
+          const CouplingMatrices& c = tk.c;
           const std::vector<double>* mats[6] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
           for (int q = 0; q < 6; ++q) {
             std::fprintf(out, "matrix %d", q);
-            for (double v : *mats[q]) put(out, v);
+            if (!summary) for (double v : *mats[q]) put(out, v);
+            else { double sum = 0.; for (double v : *mats[q]) sum += v; put(out, sum); }
             std::fprintf(out, "\n");
           }
         }
-        t_couple += ms_since(t);
       }
     }
+    t_write += ms_since(t_w);
     (void)np;
   }
   std::fclose(out);
   const double wall = ms_since(t_all);
   std::fprintf(stderr, "storm_batch: %zu blocks, %zu scans, %zu modes in %.1f ms (%.3f ms per block, %.0f modes/s) | scans %.1f ms, "
-               "eigenvectors + post-processing %.1f ms, deform %.1f ms, coupling integrals %.1f ms\n", blocks.size(), n_scans, n_modes,
-               wall, wall / std::max<size_t>(1, blocks.size()), n_modes / wall * 1e3, t_scan, t_modes, t_deform, t_couple);
+               "eigenvectors + post-processing %.1f ms, deform + coupling integrals %.1f ms (deform %.1f), writing %.1f ms\n",
+               blocks.size(), n_scans, n_modes, wall, wall / std::max<size_t>(1, blocks.size()), n_modes / wall * 1e3, t_scan, t_modes,
+               t_couple, t_deform, t_write);
   return 0;
 }
