@@ -383,6 +383,41 @@ class HipSweep:
         return res
 
 
+def _sweep_resident(self, posts, freq_lists, node_cap=None):
+    """storm_sweep_modes_resident: ids and nodes per system; the 13 fields of every mode stay in HBM for
+    coupling_matrices_resident (mode index = position in the concatenation of freq_lists)."""
+    off, f = self._flat(freq_lists)
+    npts = self.n_int + 1
+    cap = npts if node_cap is None else node_cap
+    n = f.size
+    ids = (ModeId * max(n, 1))()
+    nodes = np.full((n, max(cap, 1)), np.nan)
+    hs = (C.c_void_p * max(self.n_sys, 1))(*[q._h if q is not None else None for q in posts])
+    _check(load_library().storm_sweep_modes_resident(self._h, hs, _sp(off), _p(f), ids, _p(nodes) if cap else None, cap))
+    self._resident_freq = f
+    allr = _post_result(n, None, ids, nodes, cap)
+    return [dict(ids=allr["ids"][int(off[u]):int(off[u + 1])], n_nodes=allr["n_nodes"][int(off[u]):int(off[u + 1])],
+                 nodes=allr["nodes"][int(off[u]):int(off[u + 1])]) for u in range(self.n_sys)]
+
+
+def _sweep_coupling(self, post, mode_index, ells, m, metric):
+    """storm_sweep_coupling_matrices on resident modes; dict name -> [n, n] array indexed [left, right]."""
+    idx = np.ascontiguousarray(mode_index, dtype=np.uintp)
+    ells = np.ascontiguousarray(ells, dtype=np.uint64)
+    f = _f64(self._resident_freq[idx])
+    n = idx.size
+    arrs = [_f64(metric[k]) for k in METRIC_FIELDS]
+    md = MetricDesc(*[_p(a) for a in arrs])
+    out = np.zeros((len(COUPLING_MATRICES), n * n))
+    _check(load_library().storm_sweep_coupling_matrices(self._h, post._h, n, _sp(idx), ells.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                        _p(f), m, C.byref(md), _p(out)))
+    return {k: out[i].reshape(n, n).T.copy() for i, k in enumerate(COUPLING_MATRICES)}
+
+
+HipSweep.modes_resident = _sweep_resident
+HipSweep.coupling_matrices_resident = _sweep_coupling
+
+
 def _post_result(n, fields, ids, nodes, cap):
     idarr = np.array([[i.cross_clockwise, i.cross_counter_clockwise, i.radial_order] for i in ids[:n]],
                      dtype=np.int64).reshape(n, 3)

@@ -311,3 +311,46 @@ def test_full_size_configs_4_and_5_as_one_sweep(oracle, golden_dir):
                                         np.array([b["index"] for b in got[k][0]], dtype=np.int64)])).astype(np.int64)
         assert same_bits(o.det(grids[k][idx], threads=16), got[k][1][idx]), k
     assert got[6][0] == []                   # no radial mode below the fundamental
+
+
+def test_resident_fields_and_coupling_integrals(oracle, golden_dir):
+    """post-process + perturb-deformed with the fields staying in HBM: storm_sweep_modes_resident, then
+    storm_sweep_coupling_matrices on a subset of the modes (two systems, interleaved order), against the host-fields
+    entry point and the oracle."""
+    import storm_amd
+    from storm_amd import ffi
+    model = rotating(oracle, golden_dir, "zams", 0.08)
+    grid = model.field("r_coord")
+    cfg = [(1, 1), (0, 0), (3, 1), (2, 0), (2, 1)]
+    solvers = [oracle.Solver(model, ell, m, "colloc4", grid) for ell, m in cfg]
+    sweep = sweep_from_oracle(solvers)
+    grids = [oracle.linspace(2.0, 13.0, 70)] * len(cfg)
+    got = sweep.scan_and_optimize(grids, oracle.relative_to_ulp(1e-9))
+    roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+    post = storm_amd.HipPostproc({k: model.field(k) for k in storm_amd.MODEL_FIELDS})
+    posts = [post] * len(cfg)
+    full = sweep.modes(posts, roots, want_fields=True)
+    res = sweep.modes_resident(posts, roots)
+    off = np.concatenate([[0], np.cumsum([r.size for r in roots])])
+    for u in range(len(cfg)):
+        assert res[u]["ids"].tolist() == full[u]["ids"].tolist()
+    metric = model.perturb_structure(0.08)
+    # the m = 1 modes, systems 4, 0, 2 in that order (not the resident order)
+    pick = [(4, k) for k in range(roots[4].size)] + [(0, k) for k in range(roots[0].size)] + [(2, k) for k in range(roots[2].size)]
+    idx = np.array([off[u] + k for u, k in pick])
+    ells = np.array([cfg[u][0] for u, _ in pick], dtype=np.uint64)
+    freqs = np.array([roots[u][k] for u, k in pick])
+    fields = np.stack([full[u]["fields"][k] for u, k in pick])
+    mats = sweep.coupling_matrices_resident(post, idx, ells, 1, metric)
+    host_path = post.coupling_matrices(ells, freqs, fields, 1, metric)
+    ref, _ = model.coupling_matrices(ells, freqs, fields, 1, metric, threads=16)
+    assert idx.size >= 8
+    for k in ref:
+        assert same_bits(mats[k], host_path[k]) and same_bits(mats[k], ref[k]), k
+    # a later modes call drops the resident set
+    sweep.modes(posts, roots)
+    with pytest.raises(storm_amd.StormError, match="no resident fields"):
+        sweep.coupling_matrices_resident(post, idx, ells, 1, metric)
+    with pytest.raises(storm_amd.StormError, match="staging cap"):
+        sweep.set_option("steps_bytes_max", 1 << 20)
+        sweep.modes_resident(posts, roots)
