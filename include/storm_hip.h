@@ -230,6 +230,15 @@ int storm_sweep_coupling_matrices(storm_sweep* sweep, storm_postproc* post, size
                                   const uint64_t* ell, const double* freq, int64_t m,
                                   const storm_metric_desc* metric, double* out);
 
+/* The same for many blocks in ONE launch (a group of rotation rates): problem j owns entries
+ * [offsets[j], offsets[j+1]) of mode_index / ell / freq and has its own handle posts[j], azimuthal order m[j], metric
+ * metrics[j] and result buffer out[j] (STORM_COUPLING_MATRICES * n_j * n_j doubles).  offsets has n_problems + 1
+ * entries.  Bit-identical to n_problems calls of storm_sweep_coupling_matrices. */
+int storm_sweep_coupling_matrices_batch(storm_sweep* sweep, size_t n_problems, storm_postproc* const* posts,
+                                        const size_t* offsets, const size_t* mode_index, const uint64_t* ell,
+                                        const double* freq, const int64_t* m, const storm_metric_desc* metrics,
+                                        double* const* out);
+
 /* ---- Memory cache (no counterpart in the reference) ----
  * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
  * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent

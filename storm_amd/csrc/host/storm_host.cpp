@@ -511,6 +511,53 @@ CouplingMatrices SolverSweep::coupling_matrices(const PostProcessor& post, const
   return c;
 }
 
+std::vector<CouplingMatrices> SolverSweep::coupling_matrices(const std::vector<CouplingProblem>& problems) const {
+  const size_t np = n_int_ + 1, P = problems.size();
+  if (resident_off_.empty()) throw std::runtime_error("SolverSweep::coupling_matrices: call modes_resident first");
+  std::vector<size_t> off(P + 1, 0), index;
+  std::vector<uint64_t> ell;
+  std::vector<double> freq;
+  std::vector<int64_t> m(P);
+  std::vector<storm_metric_desc> md(P);
+  std::vector<storm_postproc*> posts(P, nullptr);
+  std::vector<std::vector<double>> outs(P);
+  std::vector<double*> out_ptr(P, nullptr);
+  for (size_t j = 0; j < P; ++j) {
+    const CouplingProblem& pr = problems[j];
+    if (!pr.model_on_grid || !pr.metric) throw std::runtime_error("coupling_matrices: null problem member");
+    const PerturbedMetric& mt = *pr.metric;
+    for (const std::vector<double>* v : {&mt.alpha, &mt.dalpha, &mt.ddalpha, &mt.beta, &mt.dbeta, &mt.ddbeta})
+      if (v->size() != np) throw std::runtime_error("coupling_matrices: metric arrays must have the model's length");
+    for (const ModeRef& r : pr.modes) {
+      if (r.system >= size() || resident_off_[r.system] + r.mode >= resident_off_[r.system + 1])
+        throw std::runtime_error("coupling_matrices: no such resident mode");
+      index.push_back(resident_off_[r.system] + r.mode);
+      ell.push_back(ell_[r.system]);
+      freq.push_back(resident_freq_[index.back()]);
+    }
+    off[j + 1] = index.size();
+    m[j] = pr.m;
+    md[j] = storm_metric_desc{mt.alpha.data(), mt.dalpha.data(), mt.ddalpha.data(), mt.beta.data(), mt.dbeta.data(), mt.ddbeta.data()};
+    posts[j] = pr.model_on_grid->handle();
+    const size_t n = pr.modes.size();
+    outs[j].resize(size_t(STORM_COUPLING_MATRICES) * n * n);
+    out_ptr[j] = outs[j].data();
+  }
+  const int rc = storm_sweep_coupling_matrices_batch(h_, P, posts.data(), off.data(), index.data(), ell.data(), freq.data(), m.data(),
+                                                     md.data(), out_ptr.data());
+  if (rc != STORM_OK) raise_abi("storm_sweep_coupling_matrices_batch", rc);
+  std::vector<CouplingMatrices> res(P);
+  for (size_t j = 0; j < P; ++j) {
+    CouplingMatrices& c = res[j];
+    const size_t n = problems[j].modes.size();
+    c.n = n;
+    std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
+    for (int q = 0; q < STORM_COUPLING_MATRICES; ++q)
+      dst[q]->assign(outs[j].begin() + size_t(q) * n * n, outs[j].begin() + size_t(q + 1) * n * n);
+  }
+  return res;
+}
+
 std::vector<std::vector<Rotating1DPostprocessing>> SolverSweep::run_modes(const std::vector<const PostProcessor*>& posts,
                                                                           const std::vector<std::vector<double>>& roots,
                                                                           bool want_fields, bool resident) const {

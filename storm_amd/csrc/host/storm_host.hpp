@@ -248,6 +248,14 @@ class SolverSweep {
   struct ModeRef { size_t system, mode; };
   CouplingMatrices coupling_matrices(const PostProcessor& model_on_grid, const std::vector<ModeRef>& modes, int64_t m,
                                      const PerturbedMetric& metric) const;
+  // many blocks (rotation rates) in one launch
+  struct CouplingProblem {
+    const PostProcessor* model_on_grid;
+    std::vector<ModeRef> modes;
+    int64_t m;
+    const PerturbedMetric* metric;
+  };
+  std::vector<CouplingMatrices> coupling_matrices(const std::vector<CouplingProblem>& problems) const;
   size_t size() const { return ell_.size(); }
   size_t len() const { return n_int_; }
   storm_sweep* handle() const { return h_; }

@@ -271,16 +271,14 @@ typedef __attribute__((address_space(1))) const void* cp_glb_ptr;
 // the last one; the weights array is padded on the host).  LDS image per plane: [point][mode], so the 8 modes of
 // one point sit in 8 consecutive doubles (conflict-free reads, each shared by 8 lanes).  One DMA instruction
 // moves 256 B = 4 points x 8 modes; lane -> (point, mode, half of the double).
-PDEV void coupling_stage(const CouplingArgs& a, size_t l0, size_t r0, size_t rc0, double* tile, int lane) {
-  const size_t np = a.n_pts, M = a.n_modes;
-  const int pt_in = lane >> 4, mode_in = (lane >> 1) & 7, word = lane & 1;
-  size_t lmode = l0 + mode_in, rmode = r0 + mode_in;
-  lmode = lmode < M ? lmode : M - 1;
-  rmode = rmode < M ? rmode : M - 1;
+// `lrow` / `rrow`: the fields row of the left / right mode this LANE stages (see coupling_body).
+PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t rc0, double* tile, int lane) {
+  const size_t np = a.n_pts;
+  const int pt_in = lane >> 4, word = lane & 1;
   constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
 #pragma unroll
   for (int pl = 0; pl < 9; ++pl) {
-    const double* row = a.fields + ((pl < 4 ? lmode : rmode) * kPostFields + kPlanes[pl]) * np;
+    const double* row = a.fields + ((pl < 4 ? lrow : rrow) * kPostFields + kPlanes[pl]) * np;
 #pragma unroll
     for (int h = 0; h < kCpChunk / 4; ++h) {
       size_t pt = rc0 + h * 4 + pt_in;
@@ -295,12 +293,22 @@ PDEV void coupling_stage(const CouplingArgs& a, size_t l0, size_t r0, size_t rc0
     __builtin_amdgcn_global_load_lds((cp_glb_ptr)(wsrc + qd * 256), (cp_lds_ptr)(tile + kCpFieldTile + qd * 32), 4, 0, 0);
 }
 
-__global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) {
+PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
   __shared__ __attribute__((aligned(16))) double tiles[2][kCpTile];
   const int lane = threadIdx.x;
   const int tl = lane >> 3, tr = lane & 7;
   const size_t M = a.n_modes, np = a.n_pts;
-  const size_t l0 = (size_t)blockIdx.x * 8, r0 = (size_t)blockIdx.y * 8;
+  const size_t l0 = (size_t)tile_l * 8, r0 = (size_t)tile_r * 8;
+  // staging: lane -> (point, mode of the tile, half of the double); the mode's row in `fields`, looked up once
+  size_t lrow, rrow;
+  {
+    const int mode_in = (lane >> 1) & 7;
+    size_t lmode = l0 + mode_in, rmode = r0 + mode_in;
+    lmode = lmode < M ? lmode : M - 1;
+    rmode = rmode < M ? rmode : M - 1;
+    lrow = a.rows ? (size_t)a.rows[lmode] : lmode;
+    rrow = a.rows ? (size_t)a.rows[rmode] : rmode;
+  }
   const bool live = l0 + tl < M && r0 + tr < M;
   const size_t lm = l0 + tl < M ? l0 + tl : M - 1, rm = r0 + tr < M ? r0 + tr : M - 1;
   const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lm] * a.n_ell + a.ell_index[rm]) * kCouplingConsts;
@@ -315,12 +323,12 @@ __global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) {
             o_rrho = 8 * kCpPlane + tr;
   double d_squared = 0.0, d_linear = 0.0, d_zero = 0.0, r_linear = 0.0, r_zero = 0.0, l_zero = 0.0;
   bool finite = true;
-  coupling_stage(a, l0, r0, 1, tiles[0], lane);
+  coupling_stage(a, lrow, rrow, 1, tiles[0], lane);
   int buf = 0;
   for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk `buf` (requested one chunk ago) has landed
     __syncthreads();
-    if (rc0 + kCpChunk < np) coupling_stage(a, l0, r0, rc0 + kCpChunk, tiles[buf ^ 1], lane);
+    if (rc0 + kCpChunk < np) coupling_stage(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
     const double* __restrict__ t = tiles[buf];
     const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
     for (int c = 0; c < cnt; ++c) {
@@ -363,6 +371,16 @@ __global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) {
   }
 }
 
+__global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) { coupling_body(a, blockIdx.x, blockIdx.y); }
+
+// blockIdx.z = problem; the grid covers the largest one, tiles past a problem's own size leave at once
+__global__ __launch_bounds__(64, 2) void coupling_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.z];
+  const size_t tiles = (a.n_modes + 7) / 8;
+  if (blockIdx.x >= tiles || blockIdx.y >= tiles) return;
+  coupling_body(a, blockIdx.x, blockIdx.y);
+}
+
 }  // namespace
 
 hipError_t launch_postprocess(const PostArgs& a) {
@@ -398,6 +416,14 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
   if (n > 65535) return hipErrorInvalidValue;
   const unsigned bx = (unsigned)std::min<size_t>((row_elems + 255) / 256, 128);
   gather_rows_kernel<<<dim3(bx, (unsigned)n, 1), 256, 0, stream>>>(src, index, row_elems, dst);
+  return hipGetLastError();
+}
+
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream) {
+  if (n_problems == 0 || max_modes == 0) return hipSuccess;
+  const unsigned tiles = (unsigned)((max_modes + 7) / 8);
+  if (tiles > 65535 || n_problems > 65535) return hipErrorInvalidValue;
+  coupling_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
   return hipGetLastError();
 }
 

@@ -83,7 +83,8 @@ enum CouplingConst : int { CQ_Q2 = 0, CQ_Q2_HRD, CQ_Q2_HLD, CQ_Q2_H, CQ_RT_P, CQ
 
 struct CouplingArgs {
   size_t n_pts, n_modes;
-  const double* fields;    // device [n_modes][13][n_pts], post-processing layout
+  const double* fields;    // device [..][13][n_pts], post-processing layout: mode k of the problem is row k, or row
+  const long long* rows;   // rows[k] when `rows` is not null (a subset of a larger resident set, no gather copy)
   const double* freq;      // device [n_modes]
   const int* ell_index;    // device [n_modes], index into the distinct-ell list
   const double* consts;    // device [n_ell][n_ell][kCouplingConsts]
@@ -94,6 +95,9 @@ struct CouplingArgs {
   hipStream_t stream;
 };
 hipError_t launch_coupling(const CouplingArgs& args);
+// Several coupling problems in one launch: blockIdx.z picks table[z] (device array; args.stream is ignored).
+// max_modes = the largest n_modes in the table.
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.

@@ -998,6 +998,77 @@ int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const do
 }  // extern "C"
 
 namespace {
+// Per-point weights of the coupling integrals: the mode-independent sub-expressions of src/perturbed.rs:88-108,157-252.
+// `w`: (n_pts + 16) * kCouplingWeights doubles (one chunk of zero padding: the kernel stages 8 points at a time).
+void coupling_weights(const storm_postproc* p, int64_t m, const storm_metric_desc* metric, double* w) {
+  const size_t np = p->model.n_pts;
+  std::memset(w, 0, (np + 16) * kCouplingWeights * sizeof(double));
+  const double mf = double(m);
+  for (size_t i = 0; i < np; ++i) {
+    double* u = w + i * kCouplingWeights;
+    const double x = p->h_r[i], rho = p->h_rho[i], rot = p->h_rot[i];
+    const double ea = metric->alpha[i], adea = metric->dalpha[i], eb = metric->beta[i], adeb = metric->dbeta[i];
+    u[CW_TR2] = p->h_trap[i] * (x * x);
+    u[CW_VOL] = p->h_trap[i] * (x * x) * rho;
+    u[CW_VOL2] = u[CW_VOL] * 2.;
+    u[CW_VOL2ROT] = u[CW_VOL] * 2. * rot;
+    u[CW_C1] = 2. * mf * rot;
+    u[CW_C2] = mf * mf * rot * rot;
+    u[CW_MROT] = mf * rot;
+    u[CW_RHO] = rho; u[CW_X] = x;
+    u[CW_U1] = 1. + 2. * (ea + adea);
+    u[CW_U2] = 1. + 2. * ea;
+    u[CW_U3] = eb + adeb;
+    u[CW_U4] = 1. + 2. * ea + adea;
+    u[CW_U5] = 2. * eb + adeb;
+    u[CW_EB] = eb;
+    u[CW_TEA] = 3. * ea + adea;
+    u[CW_ADTEA] = 3. * metric->dalpha[i] + metric->ddalpha[i];
+    u[CW_TEB] = 3. * eb + adeb;
+    u[CW_ADTEB] = 3. * metric->dbeta[i] + metric->ddbeta[i];
+  }
+}
+
+// Gaunt factors per pair of distinct degrees (src/perturbed.rs:126-146): ell_index[k] = position of ell[k] among the
+// distinct degrees, consts = [n_ell][n_ell][kCouplingConsts].  Returns n_ell.
+size_t coupling_consts(size_t n, const uint64_t* ell, int64_t m, int* ell_index, std::vector<double>& consts) {
+  std::vector<uint64_t> ells;
+  for (size_t k = 0; k < n; ++k) {
+    size_t at = 0;
+    while (at < ells.size() && ells[at] != ell[k]) ++at;
+    if (at == ells.size()) ells.push_back(ell[k]);
+    ell_index[k] = int(at);
+  }
+  const size_t ne = ells.size();
+  consts.assign(ne * ne * kCouplingConsts, 0.0);
+  for (size_t a = 0; a < ne; ++a)
+    for (size_t b = 0; b < ne; ++b) {
+      double* q = consts.data() + (a * ne + b) * kCouplingConsts;
+      const uint64_t le = ells[a], re = ells[b];
+      q[CQ_Q2] = gaunt_q_kl2(le, re, m);
+      q[CQ_Q2_HRD] = gaunt_q_kl2_hd(le, re, m);
+      q[CQ_Q2_HLD] = gaunt_q_kl2_hd(re, le, m);
+      q[CQ_Q2_H] = gaunt_q_kl2_h(le, re, m);
+      if (le == re) {
+        const uint64_t n1 = re == 0 ? 0 : re - 1;
+        q[CQ_RT_P] = gaunt_q_kl1_hd(le, re + 1, m);
+        q[CQ_RT_N] = gaunt_q_kl1_hd(le, n1, m);
+        q[CQ_HT_P] = -gaunt_q_kl1_h(le, re + 1, m);
+        q[CQ_HT_N] = -gaunt_q_kl1_h(le, n1, m);
+        q[CQ_IPR] = 1.;
+        q[CQ_IPH] = double(re * (re + 1));
+      }
+    }
+  return ne;
+}
+
+void check_metric(const storm_metric_desc* metric) {
+  if (!metric) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+  const double* ms[6] = {metric->alpha, metric->dalpha, metric->ddalpha, metric->beta, metric->dbeta, metric->ddbeta};
+  for (const double* q : ms)
+    if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null metric array");
+}
+
 // The coupling integrals of n modes whose 13 fields `provide_fields` puts into p->d_fields ([n][13][n_pts]) on the
 // given stream: an upload of host arrays (storm_coupling_matrices) or a device-side gather of fields that never left
 // HBM (storm_sweep_coupling_matrices).  Caller holds no lock; arguments are validated here.
@@ -1013,61 +1084,11 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     std::lock_guard<std::mutex> lock(p->mu);
     DeviceGuard g(p->device);
     const size_t np = p->model.n_pts;
-    // per-point weights: the mode-independent sub-expressions of src/perturbed.rs:88-108,157-252
-    std::vector<double> w((np + 16) * kCouplingWeights, 0.0);  // one chunk of zero padding: the kernel stages 16 points at a time
-    const double mf = double(m);
-    for (size_t i = 0; i < np; ++i) {
-      double* u = w.data() + i * kCouplingWeights;
-      const double x = p->h_r[i], rho = p->h_rho[i], rot = p->h_rot[i];
-      const double ea = metric->alpha[i], adea = metric->dalpha[i], eb = metric->beta[i], adeb = metric->dbeta[i];
-      u[CW_TR2] = p->h_trap[i] * (x * x);
-      u[CW_VOL] = p->h_trap[i] * (x * x) * rho;
-      u[CW_VOL2] = u[CW_VOL] * 2.;
-      u[CW_VOL2ROT] = u[CW_VOL] * 2. * rot;
-      u[CW_C1] = 2. * mf * rot;
-      u[CW_C2] = mf * mf * rot * rot;
-      u[CW_MROT] = mf * rot;
-      u[CW_RHO] = rho; u[CW_X] = x;
-      u[CW_U1] = 1. + 2. * (ea + adea);
-      u[CW_U2] = 1. + 2. * ea;
-      u[CW_U3] = eb + adeb;
-      u[CW_U4] = 1. + 2. * ea + adea;
-      u[CW_U5] = 2. * eb + adeb;
-      u[CW_EB] = eb;
-      u[CW_TEA] = 3. * ea + adea;
-      u[CW_ADTEA] = 3. * metric->dalpha[i] + metric->ddalpha[i];
-      u[CW_TEB] = 3. * eb + adeb;
-      u[CW_ADTEB] = 3. * metric->dbeta[i] + metric->ddbeta[i];
-    }
-    // Gaunt factors per pair of distinct degrees (src/perturbed.rs:126-146)
-    std::vector<uint64_t> ells;
+    std::vector<double> w((np + 16) * kCouplingWeights);
+    coupling_weights(p, m, metric, w.data());
     std::vector<int> ell_index(n);
-    for (size_t k = 0; k < n; ++k) {
-      size_t at = 0;
-      while (at < ells.size() && ells[at] != ell[k]) ++at;
-      if (at == ells.size()) ells.push_back(ell[k]);
-      ell_index[k] = int(at);
-    }
-    const size_t ne = ells.size();
-    std::vector<double> consts(ne * ne * kCouplingConsts, 0.0);
-    for (size_t a = 0; a < ne; ++a)
-      for (size_t b = 0; b < ne; ++b) {
-        double* q = consts.data() + (a * ne + b) * kCouplingConsts;
-        const uint64_t le = ells[a], re = ells[b];
-        q[CQ_Q2] = gaunt_q_kl2(le, re, m);
-        q[CQ_Q2_HRD] = gaunt_q_kl2_hd(le, re, m);
-        q[CQ_Q2_HLD] = gaunt_q_kl2_hd(re, le, m);
-        q[CQ_Q2_H] = gaunt_q_kl2_h(le, re, m);
-        if (le == re) {
-          const uint64_t n1 = re == 0 ? 0 : re - 1;
-          q[CQ_RT_P] = gaunt_q_kl1_hd(le, re + 1, m);
-          q[CQ_RT_N] = gaunt_q_kl1_hd(le, n1, m);
-          q[CQ_HT_P] = -gaunt_q_kl1_h(le, re + 1, m);
-          q[CQ_HT_N] = -gaunt_q_kl1_h(le, n1, m);
-          q[CQ_IPR] = 1.;
-          q[CQ_IPH] = double(re * (re + 1));
-        }
-      }
+    std::vector<double> consts;
+    const size_t ne = coupling_consts(n, ell, m, ell_index.data(), consts);
     const size_t nf = n * kPostFields * np;
     p->d_fields.reserve(nf, p->stream);
     p->d_freq.reserve(n, p->stream);
@@ -1086,7 +1107,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     CouplingArgs a;
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
-    a.stream = st;
+    a.rows = nullptr; a.stream = st;
     if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
     if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
     hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
@@ -1211,6 +1232,11 @@ struct storm_sweep {
   // storm_sweep_modes_resident: the 13 fields of every mode of that call stay in d_fields (internal order);
   // resident_at[i] = row of the mode the caller passed i-th.  Any other modes call drops them.
   std::vector<long long> resident_at;
+  DevBuf<double> d_cp;        // batched coupling integrals: weights, consts, frequencies, results of every problem
+  DevBuf<long long> d_cp_idx; // rows of the resident fields
+  DevBuf<int> d_cp_ell, d_cp_flags;
+  DevBuf<CouplingArgs> d_cp_table;
+  PinnedBuf h_cp;
   PinnedBuf h_in, h_out, h_flags;
   int arith = 0, hex_lanes = 0, eigen_layout = 0;
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
@@ -1513,7 +1539,8 @@ void storm_sweep_destroy(storm_sweep* q) {
   if (q->sync_marker) (void)hipEventDestroy(q->sync_marker);
   q->tab.release(); q->d_table.release(); q->d_freq.release(); q->d_det.release(); q->d_steps.release(); q->d_upper.release();
   q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
-  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
+  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release();
+  q->d_cp_table.release(); q->h_cp.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
   (void)hipSetDevice(prev);
   delete q;
 }
@@ -1789,6 +1816,112 @@ int storm_sweep_coupling_matrices(storm_sweep* q, storm_postproc* p, size_t n, c
       hip_check(hipMemcpyAsync(p->d_gather.p, rows.data(), n * sizeof(long long), hipMemcpyHostToDevice, st), "gather index H2D");
       hip_check(launch_gather_rows(resident_fields, p->d_gather.p, n, row_elems, d_fields, st), "gather launch");
     });
+  });
+}
+
+int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm_postproc* const* posts, const size_t* offsets,
+                                        const size_t* mode_index, const uint64_t* ell, const double* freq, const int64_t* m,
+                                        const storm_metric_desc* metrics, double* const* out) {
+  return guarded([&] {
+    if (!q || (n_problems && (!posts || !offsets || !m || !metrics || !out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_problems == 0) return;
+    if (n_problems > 65535) fail(STORM_ERR_INVALID_ARGUMENT, "too many problems in one call");
+    if (offsets[0] != 0) fail(STORM_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+    const size_t total = offsets[n_problems];
+    if (total && (!mode_index || !ell || !freq)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t np = q->n_int + 1;
+    size_t max_modes = 0, out_total = 0;
+    for (size_t j = 0; j < n_problems; ++j) {
+      if (offsets[j + 1] < offsets[j]) fail(STORM_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+      const size_t n = offsets[j + 1] - offsets[j];
+      if (!n) continue;
+      if (!posts[j] || !out[j]) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+      if (posts[j]->device != q->device) fail(STORM_ERR_INVALID_ARGUMENT, "sweep and post-processing handle live on different devices");
+      if (posts[j]->model.n_pts != np)
+        fail(STORM_ERR_INVALID_ARGUMENT, "the solver grid is not the post-processing model's grid (n_int + 1 != n_pts)");
+      check_metric(&metrics[j]);
+      if (n > 8 * size_t(65535)) fail(STORM_ERR_INVALID_ARGUMENT, "too many modes");
+      max_modes = std::max(max_modes, n);
+      out_total += size_t(kCouplingMatrices) * n * n;
+    }
+    if (max_modes == 0) return;
+    std::lock_guard<std::mutex> lock(q->mu);
+    DeviceGuard g(q->device);
+    if (q->resident_at.empty()) fail(STORM_ERR_INVALID_ARGUMENT, "no resident fields: call storm_sweep_modes_resident first");
+    // host image: [weights of every problem | consts of every problem | frequencies], rows and ell indices separately
+    const size_t w_elems = (np + 16) * kCouplingWeights;
+    std::vector<std::vector<double>> consts(n_problems);
+    std::vector<int> ell_index(total);
+    std::vector<size_t> n_ell(n_problems, 0), c_off(n_problems, 0);
+    size_t c_total = 0;
+    for (size_t j = 0; j < n_problems; ++j) {
+      const size_t n = offsets[j + 1] - offsets[j];
+      if (!n) continue;
+      n_ell[j] = coupling_consts(n, ell + offsets[j], m[j], ell_index.data() + offsets[j], consts[j]);
+      c_off[j] = c_total;
+      c_total += consts[j].size();
+    }
+    const size_t in_elems = n_problems * w_elems + c_total + total;
+    q->h_cp.reserve(std::max(in_elems, out_total) + 1);
+    double* hw = q->h_cp.p;
+    double* hc = hw + n_problems * w_elems;
+    double* hf = hc + c_total;
+    for (size_t j = 0; j < n_problems; ++j) {
+      const size_t n = offsets[j + 1] - offsets[j];
+      if (!n) continue;
+      coupling_weights(posts[j], m[j], &metrics[j], hw + j * w_elems);
+      std::memcpy(hc + c_off[j], consts[j].data(), consts[j].size() * sizeof(double));
+    }
+    if (total) std::memcpy(hf, freq, total * sizeof(double));
+    std::vector<long long> rows(total);
+    for (size_t k = 0; k < total; ++k) {
+      if (mode_index[k] >= q->resident_at.size()) fail(STORM_ERR_INVALID_ARGUMENT, "mode index out of range");
+      rows[k] = q->resident_at[mode_index[k]];
+    }
+    hipStream_t st = q->stream;
+    q->d_cp.reserve(in_elems + out_total, st);
+    q->d_cp_idx.reserve(total, st);
+    q->d_cp_ell.reserve(total, st);
+    q->d_cp_flags.reserve(1, st);
+    q->d_cp_table.reserve(n_problems, st);
+    double* dw = q->d_cp.p;
+    double* dc = dw + n_problems * w_elems;
+    double* df = dc + c_total;
+    double* dout = q->d_cp.p + in_elems;
+    std::vector<CouplingArgs> table(n_problems);
+    size_t out_at = 0;
+    for (size_t j = 0; j < n_problems; ++j) {
+      const size_t n = offsets[j + 1] - offsets[j];
+      CouplingArgs& a = table[j];
+      a.n_pts = np; a.n_modes = n; a.fields = q->d_fields.p; a.rows = q->d_cp_idx.p + offsets[j];
+      a.freq = df + offsets[j]; a.ell_index = q->d_cp_ell.p + offsets[j];
+      a.consts = dc + c_off[j]; a.n_ell = int(n_ell[j]); a.weights = dw + j * w_elems;
+      a.out = dout + out_at; a.flags = q->d_cp_flags.p; a.stream = st;
+      out_at += size_t(kCouplingMatrices) * n * n;
+    }
+    hip_check(hipMemcpyAsync(q->d_cp.p, q->h_cp.p, in_elems * sizeof(double), hipMemcpyHostToDevice, st), "coupling inputs H2D");
+    hip_check(hipMemcpyAsync(q->d_cp_idx.p, rows.data(), total * sizeof(long long), hipMemcpyHostToDevice, st), "rows H2D");
+    hip_check(hipMemcpyAsync(q->d_cp_ell.p, ell_index.data(), total * sizeof(int), hipMemcpyHostToDevice, st), "ell H2D");
+    hip_check(hipMemcpyAsync(q->d_cp_table.p, table.data(), n_problems * sizeof(CouplingArgs), hipMemcpyHostToDevice, st), "table H2D");
+    hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
+    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, st), "coupling launch");
+    q->stats.launches += 1;
+    // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the
+    // results only after the stream has been synchronised)
+    sync_stream(st, q->sync_marker);
+    q->h_flags.reserve(1);
+    int* flags_ptr = reinterpret_cast<int*>(q->h_flags.p);
+    hip_check(hipMemcpyAsync(q->h_cp.p, dout, out_total * sizeof(double), hipMemcpyDeviceToHost, st), "out D2H");
+    hip_check(hipMemcpyAsync(flags_ptr, q->d_cp_flags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+    sync_stream(st, q->sync_marker);
+    out_at = 0;
+    for (size_t j = 0; j < n_problems; ++j) {
+      const size_t n = offsets[j + 1] - offsets[j], cnt = size_t(kCouplingMatrices) * n * n;
+      if (cnt) std::memcpy(out[j], q->h_cp.p + out_at, cnt * sizeof(double));
+      out_at += cnt;
+    }
+    if (*flags_ptr & 1)
+      fail(STORM_ERR_NON_FINITE, "Not finite number in a coupling integral (the reference asserts, src/perturbed.rs:165-260)");
   });
 }
 

@@ -64,7 +64,8 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats",
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
            "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
-           "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices"]
+           "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices",
+           "storm_sweep_coupling_matrices_batch"]
 
 _lib = None
 

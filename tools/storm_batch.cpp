@@ -268,6 +268,10 @@ int main(int argc, char** argv) {
       std::atomic<long long> deform_us{0};
       std::string error;
       std::mutex error_mu;
+      std::vector<PerturbedMetric> metrics(tasks.size());
+      std::vector<SolverSweep::CouplingProblem> problems(tasks.size());
+      // Resident path: the threads only deform (host, as in the reference); the integrals of every block of the group
+      // then go out as ONE launch.  Host-fields path: each thread also integrates its blocks (one launch per block).
       auto work = [&] {
         for (size_t at; (at = next.fetch_add(1)) < tasks.size();) {
           try {
@@ -277,7 +281,7 @@ int main(int argc, char** argv) {
             const size_t b = tk.block;
             auto t0 = Clock::now();
             // deform: perturb_structure on the model as it was at `deform` (main.rs:840-876)
-            const PerturbedMetric metric = perturb_structure(*models.at(blk.metric_model_rot), blk.metric_rot);
+            metrics[at] = perturb_structure(*models.at(blk.metric_model_rot), blk.metric_rot);
             deform_us += (long long)(ms_since(t0) * 1e3);
             std::vector<ModeToPerturb> modes;
             std::vector<SolverSweep::ModeRef> refs;
@@ -288,9 +292,8 @@ int main(int argc, char** argv) {
                   if (resident) refs.push_back({system_of[b - g0][s], k});
                 }
             tk.n = modes.size();
-            if (!modes.empty())
-              tk.c = resident ? resident->coupling_matrices(*pps.at(pm.second), refs, pm.first, metric)
-                              : pps.at(pm.second)->coupling_matrices(modes, pm.first, metric);
+            if (resident) problems[at] = SolverSweep::CouplingProblem{pps.at(pm.second).get(), refs, pm.first, &metrics[at]};
+            else if (!modes.empty()) tk.c = pps.at(pm.second)->coupling_matrices(modes, pm.first, metrics[at]);
           } catch (const std::exception& e) {
             std::lock_guard<std::mutex> lock(error_mu);
             if (error.empty()) error = e.what();
@@ -302,6 +305,12 @@ int main(int argc, char** argv) {
       for (size_t k = 1; k < n_thr; ++k) pool.emplace_back(work);
       work();
       for (auto& th : pool) th.join();
+      if (error.empty() && resident && !tasks.empty()) {
+        try {
+          std::vector<CouplingMatrices> all = resident->coupling_matrices(problems);
+          for (size_t at = 0; at < tasks.size(); ++at) tasks[at].c = std::move(all[at]);
+        } catch (const std::exception& e) { error = e.what(); }
+      }
       if (!error.empty()) { std::fprintf(stderr, "storm_batch: %s\n", error.c_str()); return 1; }
       t_deform += double(deform_us.load()) * 1e-3 / double(std::max<size_t>(1, n_thr));
       t_couple += ms_since(t);
