@@ -69,13 +69,45 @@ def parse_output(path):
     return blocks
 
 
-def oracle_run(oracle, golden_dir):
+# every scan with the same scheme and precision: each group is ONE sweep, the fields stay in HBM and the integrals of all
+# blocks of a group (different sizes, different sets of degrees, two azimuthal orders) go out as one launch
+UNIFORM = """\
+input test-data/test-model-zams.GSM
+set-rotation-constant 0.03
+scan 1 1 2.0 12.0 60 1e-8
+scan 2 0 2.0 9.0 40 1e-8 --inverse
+scan 3 1 2.0 12.0 50 1e-8
+post-process
+deform 0.03
+perturb-deformed 1
+perturb-deformed 0
+output u-a
+set-rotation-constant 0.06
+scan 2 1 2.0 10.0 45 1e-8
+scan 4 1 2.0 10.0 45 1e-8
+post-process
+deform 0.06
+perturb-deformed 1
+output u-b
+set-rotation-constant 0.09
+scan 0 0 3.0 14.0 40 1e-8
+scan 2 0 3.0 14.0 40 1e-8
+scan 1 -1 3.0 9.0 30 1e-8
+post-process
+deform 0.09
+perturb-deformed 0
+perturb-deformed -1
+output u-c
+"""
+
+
+def oracle_run(oracle, golden_dir, text=None):
     """The command list of BATCH executed one line at a time with the CPU oracle (StormState semantics)."""
     model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_zams.npz"))
     grid = model.field("r_coord")
     blocks, cur, metric = [], {"scans": [], "coupling": []}, None
     post = None
-    for raw in BATCH.splitlines():
+    for raw in (BATCH if text is None else text).splitlines():
         w = raw.split()
         if not w or w[0].startswith("#") or w[0] == "input":
             continue
@@ -123,12 +155,13 @@ def oracle_run(oracle, golden_dir):
 
 
 @pytest.mark.skipif(not os.path.exists(TOOL), reason="tools/storm_batch.bin not built (make -C storm_amd/csrc)")
-def test_batch_pipeline_matches_line_by_line_oracle(oracle, golden_dir, tmp_path):
+@pytest.mark.parametrize("text,labels", [(BATCH, ["rate-a", "rate-b", "rate-c"]), (UNIFORM, ["u-a", "u-b", "u-c"])])
+def test_batch_pipeline_matches_line_by_line_oracle(oracle, golden_dir, tmp_path, text, labels):
     from storm_amd import ffi
     model_bin = tmp_path / "zams_model.bin"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_model_bin.py"), "zams", str(model_bin)], check=True)
     batch = tmp_path / "input"
-    batch.write_text(BATCH)
+    batch.write_text(text)
     outs = []
     for group in (1, 2, 16):
         out = tmp_path / f"out{group}.txt"
@@ -137,9 +170,19 @@ def test_batch_pipeline_matches_line_by_line_oracle(oracle, golden_dir, tmp_path
         assert r.returncode == 0, r.stderr
         outs.append(out.read_text())
     assert outs[0] == outs[1] == outs[2]     # grouping blocks changes nothing
+    # blocks are independent: three processes with one share each write the three parts of the same record
+    parts = []
+    for k in range(3):
+        out = tmp_path / f"shard{k}.txt"
+        r = subprocess.run([TOOL, str(model_bin), str(batch), str(out), "--shard", f"{k}/3", "--device", "0"], capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        parts.append(out.read_text())
+    renumber = lambda t: "\n".join(" ".join(["block", "*"] + ln.split()[2:]) if ln.startswith("block ") else ln for ln in t.splitlines())
+    assert renumber("".join(parts)) == renumber(outs[0])
     got = parse_output(tmp_path / "out2.txt")
-    ref = oracle_run(oracle, golden_dir)
-    assert [b["label"] for b in got] == [b["label"] for b in ref] == ["rate-a", "rate-b", "rate-c"]
+    ref = oracle_run(oracle, golden_dir, text)
+    assert [b["label"] for b in got] == [b["label"] for b in ref] == labels
     total = 0
     for gb, rb in zip(got, ref):
         assert len(gb["scans"]) == len(rb["scans"])

@@ -20,6 +20,8 @@
 // usage: storm_batch model.bin batch.txt out.txt [--group N] [--threads T] [--summary]
 //        N = blocks executed together (default 16), T = host threads for the per-block integrals (default 8),
 //        --summary writes one checksum per coupling matrix instead of its entries (timing runs)
+//        --shard K/N runs the K-th of N contiguous shares of the blocks (blocks are independent: one process per
+//        GPU, no communication), --device D selects the HIP device
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -38,6 +40,8 @@
 
 using namespace storm_host;
 using Clock = std::chrono::steady_clock;
+extern "C" int hipSetDevice(int device);  // libamdhip64 (already a dependency of libstorm_hip)
+
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
 namespace {
@@ -140,13 +144,21 @@ void put(FILE* f, double v) { std::fprintf(f, " %a", v); }
 
 int main(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
-  size_t group = 16, threads = 8;
+  size_t group = 16, threads = 8, shard = 0, shards = 1;
+  int device = -1;
   bool summary = false;  // --summary: one checksum per matrix instead of its n*n entries (for timing runs)
   for (int k = 4; k < argc; ++k) {
     if (!std::strcmp(argv[k], "--group") && k + 1 < argc) group = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--threads") && k + 1 < argc) threads = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--summary")) summary = true;
+    else if (!std::strcmp(argv[k], "--device") && k + 1 < argc) device = std::atoi(argv[++k]);
+    else if (!std::strcmp(argv[k], "--shard") && k + 1 < argc) {
+      if (std::sscanf(argv[++k], "%zu/%zu", &shard, &shards) != 2 || shards == 0 || shard >= shards) {
+        std::fprintf(stderr, "--shard K/N with 0 <= K < N\n"); return 2;
+      }
+    }
   }
+  if (device >= 0 && hipSetDevice(device) != 0) { std::fprintf(stderr, "storm_batch: cannot select device %d\n", device); return 2; }
   if (group == 0) group = 1;
   if (threads == 0) threads = 1;
   FILE* mf = std::fopen(argv[1], "rb");
@@ -160,7 +172,12 @@ int main(int argc, char** argv) {
                                                             a[5].data(), a[6].data(), rs, msx);
   const std::vector<double> grid = base.dimensionless.r_coord;  // Model::grid with resample 1
   const size_t np = grid.size();
-  const std::vector<Block> blocks = parse(argv[2]);
+  std::vector<Block> blocks = parse(argv[2]);
+  if (shards > 1) {  // blocks are independent: process K of N takes a contiguous share (one process per GPU)
+    const size_t base = blocks.size() / shards, extra = blocks.size() % shards;
+    const size_t lo = shard * base + std::min(shard, extra), cnt = base + (shard < extra ? 1 : 0);
+    blocks = std::vector<Block>(blocks.begin() + lo, blocks.begin() + lo + cnt);
+  }
   FILE* out = std::fopen(argv[3], "w");
   if (!out) { std::perror(argv[3]); return 2; }
 
