@@ -142,7 +142,7 @@ void put(FILE* f, double v) { std::fprintf(f, " %a", v); }
 
 }  // namespace
 
-int main(int argc, char** argv) {
+static int run(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
   size_t group = 16, threads = 8, shard = 0, shards = 1;
   int device = -1;
@@ -241,6 +241,8 @@ int main(int argc, char** argv) {
         }
         auto sweep_ptr = std::make_unique<SolverSweep>(systems, DifferenceSchemes(kv.first), grid);
         SolverSweep& sweep = *sweep_ptr;
+        // eigenvector staging for all modes of the group in one pass (2 MB per mode at 6199 intervals; the card has 288 GB)
+        storm_sweep_set_option(sweep.handle(), "steps_bytes_max", int64_t(64) << 30);
         const auto res = sweep.scan_and_optimize(grids, Precision::Relative(pv.first));
         t_scan += ms_since(t); t = Clock::now();
         std::vector<std::vector<double>> roots(rs2.size());
@@ -374,4 +376,13 @@ int main(int argc, char** argv) {
                blocks.size(), n_scans, n_modes, wall, wall / std::max<size_t>(1, blocks.size()), n_modes / wall * 1e3, t_scan, t_modes,
                t_couple, t_deform, t_write);
   return 0;
+}
+
+int main(int argc, char** argv) {
+  try {
+    return run(argc, argv);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "storm_batch: %s (a smaller --group needs less device memory per pass)\n", e.what());
+    return 1;
+  }
 }
