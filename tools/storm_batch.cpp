@@ -20,6 +20,8 @@
 // usage: storm_batch model.bin batch.txt out.txt [--group N] [--threads T] [--summary]
 //        N = blocks executed together (default 16), T = host threads for the per-block integrals (default 8),
 //        --summary writes one checksum per coupling matrix instead of its entries (timing runs)
+//        --pipeline P runs P groups side by side from P host threads (default 2; the phase times printed at the end
+//        are then sums over overlapping groups)
 //        --shard K/N runs the K-th of N contiguous shares of the blocks (blocks are independent: one process per
 //        GPU, no communication), --device D selects the HIP device
 #include <atomic>
@@ -144,12 +146,13 @@ void put(FILE* f, double v) { std::fprintf(f, " %a", v); }
 
 static int run(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
-  size_t group = 16, threads = 8, shard = 0, shards = 1;
+  size_t group = 16, threads = 8, shard = 0, shards = 1, pipeline = 2;
   int device = -1;
   bool summary = false;  // --summary: one checksum per matrix instead of its n*n entries (for timing runs)
   for (int k = 4; k < argc; ++k) {
     if (!std::strcmp(argv[k], "--group") && k + 1 < argc) group = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--threads") && k + 1 < argc) threads = std::strtoul(argv[++k], nullptr, 10);
+    else if (!std::strcmp(argv[k], "--pipeline") && k + 1 < argc) pipeline = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--summary")) summary = true;
     else if (!std::strcmp(argv[k], "--device") && k + 1 < argc) device = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--shard") && k + 1 < argc) {
@@ -178,13 +181,27 @@ static int run(int argc, char** argv) {
     const size_t lo = shard * base + std::min(shard, extra), cnt = base + (shard < extra ? 1 : 0);
     blocks = std::vector<Block>(blocks.begin() + lo, blocks.begin() + lo + cnt);
   }
-  FILE* out = std::fopen(argv[3], "w");
-  if (!out) { std::perror(argv[3]); return 2; }
+  FILE* final_out = std::fopen(argv[3], "w");
+  if (!final_out) { std::perror(argv[3]); return 2; }
 
+  // Every group in flight stages ~2.7 MB per mode (step matrices, factors, eigenvectors, fields): let the library keep
+  // those blocks between groups instead of returning them to HIP (hipFree synchronises the device).
+  storm_memory_cache_limit(size_t(160) << 30, size_t(8) << 30);
   const auto t_all = Clock::now();
-  double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0, t_write = 0;
-  size_t n_scans = 0, n_modes = 0;
-  for (size_t g0 = 0; g0 < blocks.size(); g0 += group) {
+  struct Totals { double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0, t_write = 0; size_t n_scans = 0, n_modes = 0; } tot;
+  std::mutex tot_mu;
+  const size_t n_groups = (blocks.size() + group - 1) / group;
+  std::vector<std::string> records(n_groups);
+  // One group of blocks: everything from solver construction to the group's records (kept in memory so that groups can
+  // run side by side and still be written in input order).
+  auto process_group = [&](size_t gi) -> int {
+    const size_t g0 = gi * group;
+    double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0, t_write = 0;
+    size_t n_scans = 0, n_modes = 0;
+    char* mem = nullptr;
+    size_t mem_len = 0;
+    FILE* out = open_memstream(&mem, &mem_len);
+    if (!out) { std::perror("open_memstream"); return 1; }
     const size_t g1 = std::min(blocks.size(), g0 + group);
     // one model (and one post-processing handle) per distinct rotation constant of the group
     std::map<double, std::unique_ptr<DiscreteModel>> models;
@@ -368,8 +385,45 @@ static int run(int argc, char** argv) {
     }
     t_write += ms_since(t_w);
     (void)np;
+    std::fclose(out);
+    records[gi].assign(mem, mem_len);
+    std::free(mem);
+    std::lock_guard<std::mutex> lock(tot_mu);
+    tot.t_scan += t_scan; tot.t_modes += t_modes; tot.t_deform += t_deform; tot.t_couple += t_couple; tot.t_write += t_write;
+    tot.n_scans += n_scans; tot.n_modes += n_modes;
+    return 0;
+  };
+  // Groups are independent too: `pipeline` host threads each take the next group, so the host side of one group (model
+  // interpolation, plane construction, weights, result copies: about half of a group's wall time) overlaps the
+  // kernels of another.
+  {
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::string error;
+    std::mutex error_mu;
+    auto worker = [&] {
+      for (size_t gi; !failed.load() && (gi = next.fetch_add(1)) < n_groups;) {
+        try {
+          if (process_group(gi) != 0) failed = 1;
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> lock(error_mu);
+          if (error.empty()) error = e.what();
+          failed = 1;
+        }
+      }
+    };
+    const size_t n_thr = std::max<size_t>(1, std::min(pipeline, n_groups));
+    std::vector<std::thread> pool;
+    for (size_t k = 1; k < n_thr; ++k) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+    if (!error.empty()) throw std::runtime_error(error);
+    if (failed.load()) return 1;
   }
-  std::fclose(out);
+  for (const std::string& r : records) std::fwrite(r.data(), 1, r.size(), final_out);
+  std::fclose(final_out);
+  const double t_scan = tot.t_scan, t_modes = tot.t_modes, t_deform = tot.t_deform, t_couple = tot.t_couple, t_write = tot.t_write;
+  const size_t n_scans = tot.n_scans, n_modes = tot.n_modes;
   const double wall = ms_since(t_all);
   std::fprintf(stderr, "storm_batch: %zu blocks, %zu scans, %zu modes in %.1f ms (%.3f ms per block, %.0f modes/s) | scans %.1f ms, "
                "eigenvectors + post-processing %.1f ms, deform + coupling integrals %.1f ms (deform %.1f), writing %.1f ms\n",
