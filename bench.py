@@ -331,6 +331,29 @@ def main():
                  "note": "all systems advance in lock-step: one launch per phase over every (system, frequency) pair "
                          "or mode; bit-identical to one handle per system (tests/test_hip_sweep.py); one handle per "
                          "system on 16 host threads: tools/many_scans.cpp, DESIGN.md section 11"}
+    # The same kind of workload driven from the reference's batch-input language by tools/storm_batch (a child process):
+    # 64 rotation rates x (8 scans + post-process + deform + perturb-deformed), groups of 32 blocks, two groups in flight.
+    batch = None
+    tool = os.path.join(ROOT, "tools", "storm_batch.bin")
+    if rank == 0 and not args.no_sweep and os.path.exists(tool):
+        import re
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            mb, bt = os.path.join(tmp, "tams_model.bin"), os.path.join(tmp, "batch.txt")
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_model_bin.py"), "tams", mb], check=True,
+                           stdout=subprocess.DEVNULL)
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_sweep_batch.py"), bt, "64"], check=True)
+            r = subprocess.run([tool, mb, bt, os.path.join(tmp, "out.txt"), "--group", "32", "--summary", "--device", str(local_rank)],
+                               capture_output=True, text=True, timeout=300)
+            mt = re.search(r"(\d+) blocks, (\d+) scans, (\d+) modes in ([0-9.]+) ms", r.stderr)
+            if r.returncode == 0 and mt:
+                nb, ns, nm, ms = int(mt.group(1)), int(mt.group(2)), int(mt.group(3)), float(mt.group(4))
+                batch = {"rotation_rates": nb, "scans": ns, "modes": nm, "wall_ms": ms, "ms_per_rotation_rate": round(ms / nb, 3),
+                         "modes_per_s": round(nm / ms * 1e3, 1),
+                         "note": "per rate: set-rotation-constant, 8 scans (300 / 100 frequencies), post-process, deform, "
+                                 "perturb-deformed (coupling integrals of ~238 modes), records with one checksum per "
+                                 "matrix; includes process start and first-touch allocations; DESIGN.md section 11c"}
     kernel_summary, roofline = res["kernels"], res["roofline"]
 
     if rank == 0:
@@ -349,6 +372,7 @@ def main():
             "arithmetic": args.arithmetic, "kernels": kernel_summary, "roofline": roofline,
             "post_processing": post,
             "rotation_sweep": sweep,
+            "batch_pipeline": batch,
         }
         if other is not None:
             oname = "parity" if main_arith else "fast"
