@@ -275,7 +275,7 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16/32-lanes-per-frequency fused kernel
  *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default) the one whose wave count packs the
  *                GPU's wave slots better for this batch, 16, or 32
- *   "eigen_layout": eigenvector kernels: 0 (default) one wave per mode below 1536 modes per launch and one lane per
+ *   "eigen_layout": eigenvector kernels: 0 (default) one wave per mode below 1920 modes per launch and one lane per
  *                   mode from there on, 1 always wave per mode, 2 always lane per mode (same bits either way)
  *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
  *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)

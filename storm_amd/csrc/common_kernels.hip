@@ -704,9 +704,9 @@ __global__ __launch_bounds__(64) void eigen_backsub_lanes_kernel(size_t n_int, s
 // 1 = ell == 0 for every mode, 2 = mixed (lane-per-mode kernels only: their one ell-dependent expression is selected
 // per lane, so the modes of every system of a sweep go out in ONE launch).
 bool eigen_uses_lanes(size_t n, int layout) {
-  // wave per mode: ~4.6 ms per 6199 intervals while every wave has a SIMD to itself (1024 modes), then linear in n;
-  // lane per mode: ~2x that per wave, but for 64 modes
-  return layout == 2 || (layout == 0 && n >= 1536);
+  // wave per mode: ~4.6 + 1.1 ms per 6199 intervals while every wave has a SIMD to itself (1024 modes), then linear in
+  // n (13.1 ms at 2061 modes); lane per mode: 9.6 + 2.5 ms for any count up to 64 per SIMD: they cross near 1900
+  return layout == 2 || (layout == 0 && n >= 1920);
 }
 hipError_t launch_eigen(const SystemDev& s, int ell_class, const double* freq, size_t n, const double* steps,
                         double* upper, int* swaps, double* det_out, double* vec, hipStream_t stream,

@@ -238,7 +238,7 @@ def test_sweep_argument_errors(oracle, oracle_models):
     ("zams", 0, 0, None, "colloc4"), ("zams", 2, 1, 0.1, "colloc2"), ("tams", 1, -1, 0.05, "magnus2"),
     ("zams", 3, 0, lambda x: 0.05 + 0.1 * np.exp(-3.0 * x), "colloc6")])
 def test_lane_per_mode_eigen_kernels(oracle, golden_dir, name, ell, m, rot, scheme):
-    """The lane-per-mode elimination / back-substitution (picked for launches of >= 1536 modes, forced here) against the
+    """The lane-per-mode elimination / back-substitution (picked for launches of >= 1920 modes, forced here) against the
     oracle: 150 frequencies (three waves, the last one ragged), roots and non-roots alike."""
     import storm_amd
     model = rotating(oracle, golden_dir, name, rot)
@@ -292,7 +292,7 @@ def test_full_size_configs_4_and_5_as_one_sweep(oracle, golden_dir):
     assert n_modes >= 150, n_modes
     vecs = sweep.eigenvector(roots)          # wave per mode at this count
     sweep.set_option("eigen_layout", 2)
-    lane_vecs = sweep.eigenvector(roots)     # what a launch of >= 1536 modes takes
+    lane_vecs = sweep.eigenvector(roots)     # what a launch of >= 1920 modes takes
     for a, b in zip(vecs, lane_vecs):
         assert same_bits(a[0], b[0]) and same_bits(a[1], b[1])
     rng = np.random.default_rng(17)
