@@ -1463,26 +1463,23 @@ int storm_sweep_create(const storm_system_desc* descs, size_t n_sys, storm_sweep
     hip_check(hipGetDevice(&q->device), "hipGetDevice");
     q->scheme = d0.scheme; q->n_sys = n_sys; q->n_int = d0.n_int; q->p = d0.p;
     const size_t elems = planes_elems(q->n_int, q->p);
-    // planes of every system, built straight into the pinned block the upload is staged from (caller order first:
-    // the class of a system is only known once its planes are)
-    q->h_in.reserve(elems * n_sys);
+    // The kernel class of a system (ell == 0 / bitwise-uniform m*rot / general) decides its internal position; it follows
+    // from the descriptor alone (same test as build_planes).
     std::vector<char> uniform(n_sys, 1);
     std::vector<double> rotm0(n_sys, 0.0);
-    {
-      const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-      const size_t n_thr = std::min<size_t>({n_sys, hw, size_t(16)});
-      std::atomic<size_t> next{0};
-      auto work = [&] {
-        for (size_t u; (u = next.fetch_add(1)) < n_sys;) {
-          bool uni = true;
-          build_planes(descs[u], q->h_in.p + u * elems, uni, rotm0[u]);
-          uniform[u] = uni ? 1 : 0;
-        }
-      };
-      std::vector<std::thread> pool;
-      for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work);
-      work();
-      for (auto& th : pool) th.join();
+    for (size_t u = 0; u < n_sys; ++u) {
+      const storm_system_desc& d = descs[u];
+      const double mm = double(d.m);
+      const size_t cnt = d.n_int * d.p;
+      rotm0[u] = cnt ? mm * d.rot[0] : 0.0;
+      uint64_t first;
+      std::memcpy(&first, &rotm0[u], 8);
+      for (size_t k = 0; k < cnt && uniform[u]; ++k) {
+        const double v = mm * d.rot[k];
+        uint64_t b;
+        std::memcpy(&b, &v, 8);
+        if (b != first) uniform[u] = 0;
+      }
     }
     std::vector<int> cls(n_sys);
     for (size_t u = 0; u < n_sys; ++u) cls[u] = descs[u].ell == 0 ? 0 : (uniform[u] ? 1 : 2);
@@ -1496,11 +1493,35 @@ int storm_sweep_create(const storm_system_desc* descs, size_t n_sys, storm_sweep
     q->d_table.reserve(n_sys, nullptr);
     q->h_table.resize(n_sys);
     q->ell.resize(n_sys); q->m.resize(n_sys);
+    // Planes are built (a few host threads) straight into a pinned block and uploaded from there, a slab of systems at
+    // a time so that a sweep of thousands of systems does not pin gigabytes of host memory.
+    const size_t slab = std::max<size_t>(1, std::min<size_t>(n_sys, (size_t(256) << 20) / (elems * sizeof(double))));
+    q->h_in.reserve(elems * slab);
+    for (size_t k0 = 0; k0 < n_sys; k0 += slab) {
+      const size_t k1 = std::min(n_sys, k0 + slab);
+      if (k0) sync_stream(q->stream, q->sync_marker);  // the previous slab has left the pinned block
+      {
+        const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+        const size_t n_thr = std::min<size_t>({k1 - k0, hw, size_t(16)});
+        std::atomic<size_t> next{k0};
+        auto work = [&] {
+          for (size_t k; (k = next.fetch_add(1)) < k1;) {
+            bool uni = true;
+            double r0 = 0.0;
+            build_planes(descs[q->order[k]], q->h_in.p + (k - k0) * elems, uni, r0);
+          }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+      }
+      hip_check(hipMemcpyAsync(q->tab.p + k0 * elems, q->h_in.p, (k1 - k0) * elems * sizeof(double), hipMemcpyHostToDevice,
+                               q->stream), "planes H2D");
+    }
     for (size_t k = 0; k < n_sys; ++k) {
       const size_t u = q->order[k];
       const storm_system_desc& d = descs[u];
-      hip_check(hipMemcpyAsync(q->tab.p + k * elems, q->h_in.p + u * elems, elems * sizeof(double), hipMemcpyHostToDevice,
-                               q->stream), "planes H2D");
       SystemDev& sd = q->h_table[k];
       const double ell = double(d.ell);
       sd.tab = q->tab.p + k * elems;

@@ -354,3 +354,20 @@ def test_resident_fields_and_coupling_integrals(oracle, golden_dir):
     with pytest.raises(storm_amd.StormError, match="staging cap"):
         sweep.set_option("steps_bytes_max", 1 << 20)
         sweep.modes_resident(posts, roots)
+
+
+def test_sweep_of_many_systems_uploads_in_slabs(oracle, golden_dir):
+    """900 systems (more than one 256 MB upload slab of zams/Colloc2 planes), all three kernel classes interleaved."""
+    from storm_amd import ffi
+    models = [rotating(oracle, golden_dir, "zams", rot) for rot in (None, 0.05, lambda x: 0.02 + 0.03 * x)]
+    grid = models[0].field("r_coord")
+    combos = [(0, 0), (1, 0), (1, 1), (2, -1), (2, 2), (3, 0)]
+    distinct = [oracle.Solver(mdl, ell, m, "colloc2", grid) for mdl in models for ell, m in combos]
+    systems = [(distinct[k % len(distinct)].ell, distinct[k % len(distinct)].m, distinct[k % len(distinct)].system()) for k in range(900)]
+    sweep = ffi.HipSweep(distinct[0].scheme, systems, distinct[0].n_int, distinct[0].p)
+    freqs = [np.array([2.0 + 0.01 * k, 5.5, 9.25 - 0.003 * k]) for k in range(900)]
+    got = sweep.det(freqs)
+    for k in list(range(0, 900, 37)) + [899]:
+        assert same_bits(got[k], distinct[k % len(distinct)].det(freqs[k])), k
+    for k in range(len(distinct), 900):        # the middle frequency is the same for every copy of a system
+        assert bits(got[k][1]) == bits(got[k % len(distinct)][1]), k
