@@ -73,7 +73,13 @@ class MemoryCache {
   static size_t size_class(size_t bytes) {
     if (bytes <= 256) return 256;
     if (bytes < (size_t(1) << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
-    return (bytes + (size_t(1) << 20) - 1) >> 20 << 20;
+    if (bytes < (size_t(64) << 20)) return (bytes + (size_t(1) << 20) - 1) >> 20 << 20;
+    // large blocks: eight classes per power of two, so that the slightly different sizes successive handles ask for
+    // (a sweep's staging follows its mode count) land in the same class and are reused instead of allocated afresh
+    size_t p2 = size_t(1) << 26;
+    while ((p2 << 1) <= bytes) p2 <<= 1;
+    const size_t step = p2 >> 3;
+    return (bytes + step - 1) / step * step;
   }
   void* take(bool pinned, int dev, size_t bytes, size_t& granted) {
     granted = size_class(bytes);
@@ -81,7 +87,7 @@ class MemoryCache {
       std::lock_guard<std::mutex> lock(mu_);
       auto& m = blocks_[key(pinned, dev)];
       auto it = m.lower_bound(granted);
-      if (it != m.end() && it->first <= granted + granted / 4 + (size_t(1) << 20)) {  // close enough in size
+      if (it != m.end() && it->first <= granted + granted / 2 + (size_t(1) << 20)) {  // close enough in size
         void* p = it->second;
         granted = it->first;
         cached_[pinned] -= granted;

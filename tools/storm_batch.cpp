@@ -20,7 +20,7 @@
 // usage: storm_batch model.bin batch.txt out.txt [--group N] [--threads T] [--summary]
 //        N = blocks executed together (default 16), T = host threads for the per-block integrals (default 8),
 //        --summary writes one checksum per coupling matrix instead of its entries (timing runs)
-//        --pipeline P runs P groups side by side from P host threads (default 2; the phase times printed at the end
+//        --pipeline P runs P groups side by side from P host threads (default 4; the phase times printed at the end
 //        are then sums over overlapping groups)
 //        --shard K/N runs the K-th of N contiguous shares of the blocks (blocks are independent: one process per
 //        GPU, no communication), --device D selects the HIP device
@@ -146,7 +146,7 @@ void put(FILE* f, double v) { std::fprintf(f, " %a", v); }
 
 static int run(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
-  size_t group = 16, threads = 8, shard = 0, shards = 1, pipeline = 2;
+  size_t group = 16, threads = 8, shard = 0, shards = 1, pipeline = 4;
   int device = -1;
   bool summary = false;  // --summary: one checksum per matrix instead of its n*n entries (for timing runs)
   for (int k = 4; k < argc; ++k) {
