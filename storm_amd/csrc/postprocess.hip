@@ -316,6 +316,9 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
   const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
   const double k6 = ipr + 6.0 * q2;
+  // degrees more than 2 apart: the second-order Gaunt factors vanish (typical for most of an 8 x 8 tile at once, the
+  // modes arrive sorted by degree); wave-uniform so that the division count below is a scalar branch
+  const bool no_q2 = __all(q2 == 0.0 && q2_hrd == 0.0);
   const double rfreq = a.freq[rm];
   // this lane's values inside a tile: plane pl, point c, mode k at pl*kCpPlane + c*8 + k
   const int o_lxr = 0 * kCpPlane + tl, o_lxh = 1 * kCpPlane + tl, o_lpsi = 2 * kCpPlane + tl, o_lp = 3 * kCpPlane + tl;
@@ -356,7 +359,15 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
       // the six divisions by r share one refined reciprocal (shared_div.hpp: same bits as six real divisions)
       double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
                       lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
-      shared_div6(dv, shared_div_prepare(x));
+      if (no_q2) {
+        // dv[1], dv[3], dv[4], dv[5] carry a factor q2 or q2_hrd that is zero for every lane of this wave: they are
+        // +-0 (or NaN) and dividing them by the radius (finite, > 0 from the second grid point on) returns them
+        // unchanged, so only two quotients are left.  (Without this the zero numerators fail the exponent test of
+        // the shared reciprocal and the whole wave takes six full divisions per point.)
+        shared_div2(dv[0], dv[2], shared_div_prepare(x));
+      } else {
+        shared_div6(dv, shared_div_prepare(x));
+      }
       l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
                              lpsi * rrho * tea - dv[0] + lpsi * q2 * rrho * teb - dv[1] - dv[2] - dv[3] - dv[4] + dv[5]);
       finite = finite && isfinite(l_zero);

@@ -67,4 +67,20 @@ __device__ __forceinline__ void shared_div6(double (&n)[6], const SharedDenomina
   }
 }
 
+// Two quotients, same contract as shared_div6.
+__device__ __forceinline__ void shared_div2(double& n0, double& n1, const SharedDenominator& d) {
+  const unsigned w0 = unsigned(__double2hiint(n0)) & 0x7fffffffu, w1 = unsigned(__double2hiint(n1)) & 0x7fffffffu;
+  const unsigned lo = w0 < w1 ? w0 : w1, hi = w0 < w1 ? w1 : w0;
+  const bool ok = d.ok && lo >= (unsigned(1023 - 400) << 20) && hi < (unsigned(1023 + 401) << 20);
+  if (__all(ok)) {
+    const double q0 = n0 * d.r, q1 = n1 * d.r;
+    const double e0 = __builtin_fma(-d.x, q0, n0), e1 = __builtin_fma(-d.x, q1, n1);
+    n0 = __builtin_fma(e0, d.r, q0);
+    n1 = __builtin_fma(e1, d.r, q1);
+  } else {
+    n0 = n0 / d.x;
+    n1 = n1 / d.x;
+  }
+}
+
 }  // namespace storm
