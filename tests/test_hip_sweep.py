@@ -371,3 +371,24 @@ def test_sweep_of_many_systems_uploads_in_slabs(oracle, golden_dir):
         assert same_bits(got[k], distinct[k % len(distinct)].det(freqs[k])), k
     for k in range(len(distinct), 900):        # the middle frequency is the same for every copy of a system
         assert bits(got[k][1]) == bits(got[k % len(distinct)][1]), k
+
+
+def test_sweep_invalid_numbers_are_per_system(oracle, oracle_models):
+    """A non-finite discriminant (frequency 0 with ell != 0 divides by zero like the reference) drops the pair and raises
+    the flag of THAT system only (reference src/dynamic_interface.rs:130-137,153-157)."""
+    model = oracle_models("zams")
+    grid = model.field("r_coord")
+    solvers = [oracle.Solver(model, ell, 0, "colloc2", grid) for ell in (2, 1, 0, 3)]
+    grids = [np.array([0.0, 1.0, 2.0, 3.0, 4.0, 5.0]), oracle.linspace(1.0, 6.0, 9), np.array([0.0, 2.0, 4.0, 6.0]),
+             np.array([1.5, 0.0, 2.5, 3.5, 4.5])]
+    sweep = sweep_from_oracle(solvers)
+    got = sweep.scan_and_optimize(grids, 1)
+    flags = []
+    for k, o in enumerate(solvers):
+        ref, rdets, rinv = o.scan_and_optimize(grids[k], 1)
+        br, dets, inv = got[k]
+        assert np.array_equal(np.isnan(rdets), np.isnan(dets)) and np.array_equal(np.isinf(rdets), np.isinf(dets)), k
+        fin = np.isfinite(rdets)
+        assert same_bits(rdets[fin], dets[fin]) and inv == rinv and same_brackets(ref, br), k
+        flags.append(inv)
+    assert flags[0] and not flags[1]      # the sweep does not smear one system's warning over the others
