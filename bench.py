@@ -387,6 +387,7 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 ran the extra legs: leave together
         dist.destroy_process_group()
 
 
