@@ -28,4 +28,6 @@ raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
 f, e, fl = freqs[sel], ells[sel], np.ascontiguousarray(fields[sel])
 for _ in range(reps):
     out = raw.coupling_matrices(e, f, fl, 0, metric)
-print("ok", M, raw.last_kernel_ms(), "ms", float(out["d_squared"][0, 0]))
+import hashlib
+digest = hashlib.md5(b"".join(np.ascontiguousarray(out[k]).tobytes() for k in ffi.COUPLING_MATRICES)).hexdigest()
+print("ok", M, raw.last_kernel_ms(), "ms", float(out["d_squared"][0, 0]), digest)

@@ -251,10 +251,12 @@ __global__ __launch_bounds__(64) void post_modes_kernel(PostModelDev md, PostPar
 // radial grid of 148 flops of products of the left and right modes' post-processing fields.
 // Lane = one (left, right) pair, wave = 8 x 8 tile of pairs; every lane walks the grid in index order with its
 // six accumulators (the reference's `+=` loop: a sequential sum), so results are bit-identical.
-// Staging: per chunk of 8 grid points the wave needs 4 fields of its 8 left modes, 5 of its 8 right modes
-// and the 8 x 20 mode-independent weights; they are copied global -> LDS by LDS-DMA
-// (global_load_lds_dword: no VGPRs, any 4-byte alignment) one chunk ahead of the arithmetic, so the serial walk
-// never waits for memory.  FP64 VALU bound (148 flops per (pair, point); fields are read once per 8 x 8 tile).
+// Staging: per chunk of 8 grid points the wave needs 4 fields of its 8 left modes and 5 of its 8 right modes; they
+// are copied global -> LDS by LDS-DMA (global_load_lds_dword: no VGPRs, any 4-byte alignment) one chunk ahead of
+// the arithmetic, so the serial walk never waits for memory.  The 19 mode-independent weights of a point have a
+// wave-uniform address: they are read through the constant address space (s_load, scalar cache) into SGPRs and feed
+// the FP64 instructions as scalar operands -- no LDS broadcast (that was 20 of 29 LDS reads per point), 28 fewer
+// VGPRs (121: four waves per SIMD).  FP64 VALU bound (148 flops per (pair, point); fields are read once per tile).
 // No MFMA: the contraction could be phrased as ~20 weighted GEMMs, but MFMA accumulates with fused multiply-adds
 // in its own order and would change the last bits of every element; FP64 MFMA has the same peak as the FP64
 // vector pipe on MI355X, so the only cost of staying on the VALU is the un-fused mul/add split.
@@ -262,13 +264,12 @@ __global__ __launch_bounds__(64) void post_modes_kernel(PostModelDev md, PostPar
 constexpr int kCpChunk = 8;                                      // grid points per staged chunk
 constexpr int kCpPlane = kCpChunk * 8;                           // doubles: [point][mode of the tile]
 constexpr int kCpFieldTile = 9 * kCpPlane;                       // 4 left + 5 right planes
-constexpr int kCpTile = kCpFieldTile + kCpChunk * kCouplingWeights;
 
 typedef __attribute__((address_space(3))) void* cp_lds_ptr;
 typedef __attribute__((address_space(1))) const void* cp_glb_ptr;
 
-// Requests chunk [rc0, rc0 + 8) of everything this wave needs into `tile` (points past the grid are clamped to
-// the last one; the weights array is padded on the host).  LDS image per plane: [point][mode], so the 8 modes of
+// Requests chunk [rc0, rc0 + 8) of the fields this wave needs into `tile` (points past the grid are clamped to
+// the last one).  LDS image per plane: [point][mode], so the 8 modes of
 // one point sit in 8 consecutive doubles (conflict-free reads, each shared by 8 lanes).  One DMA instruction
 // moves 256 B = 4 points x 8 modes; lane -> (point, mode, half of the double).
 // `lrow` / `rrow`: the fields row of the left / right mode this LANE stages (see coupling_body).
@@ -287,19 +288,17 @@ PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t
       __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + h * 32), 4, 0, 0);
     }
   }
-  const char* wsrc = reinterpret_cast<const char*>(a.weights + rc0 * kCouplingWeights) + lane * 4;
-#pragma unroll
-  for (int qd = 0; qd < kCpChunk * kCouplingWeights * 8 / 256; ++qd)
-    __builtin_amdgcn_global_load_lds((cp_glb_ptr)(wsrc + qd * 256), (cp_lds_ptr)(tile + kCpFieldTile + qd * 32), 4, 0, 0);
 }
 
+// weights: uniform address, constant address space -> scalar loads
+typedef const double __attribute__((address_space(4))) * cp_const_ptr;
+
 PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
-  __shared__ __attribute__((aligned(16))) double tiles[2][kCpTile];
+  __shared__ __attribute__((aligned(16))) double tiles[2][kCpFieldTile];
   const int lane = threadIdx.x;
   const int tl = lane >> 3, tr = lane & 7;
   const size_t M = a.n_modes, np = a.n_pts;
   const size_t l0 = (size_t)tile_l * 8, r0 = (size_t)tile_r * 8;
-  // staging: lane -> (point, mode of the tile, half of the double); the mode's row in `fields`, looked up once
   size_t lrow, rrow;
   {
     const int mode_in = (lane >> 1) & 7;
@@ -316,29 +315,30 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
   const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
   const double k6 = ipr + 6.0 * q2;
-  // degrees more than 2 apart: the second-order Gaunt factors vanish (typical for most of an 8 x 8 tile at once, the
-  // modes arrive sorted by degree); wave-uniform so that the division count below is a scalar branch
   const bool no_q2 = __all(q2 == 0.0 && q2_hrd == 0.0);
   const double rfreq = a.freq[rm];
-  // this lane's values inside a tile: plane pl, point c, mode k at pl*kCpPlane + c*8 + k
-  const int o_lxr = 0 * kCpPlane + tl, o_lxh = 1 * kCpPlane + tl, o_lpsi = 2 * kCpPlane + tl, o_lp = 3 * kCpPlane + tl;
-  const int o_rxr = 4 * kCpPlane + tr, o_rxh = 5 * kCpPlane + tr, o_rtp = 6 * kCpPlane + tr, o_rtn = 7 * kCpPlane + tr,
-            o_rrho = 8 * kCpPlane + tr;
+  const cp_const_ptr wts = (cp_const_ptr)a.weights;
   double d_squared = 0.0, d_linear = 0.0, d_zero = 0.0, r_linear = 0.0, r_zero = 0.0, l_zero = 0.0;
   bool finite = true;
+  // this lane's nine values of point c of a tile: planes 0-3 at mode tl, 4-8 at mode tr
+  auto fetch = [&](const double* __restrict__ t, int c, double (&f)[9]) {
+#pragma unroll
+    for (int pl = 0; pl < 9; ++pl) f[pl] = t[pl * kCpPlane + c * 8 + (pl < 4 ? tl : tr)];
+  };
   coupling_stage(a, lrow, rrow, 1, tiles[0], lane);
   int buf = 0;
   for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk `buf` (requested one chunk ago) has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (rc0 + kCpChunk < np) coupling_stage(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
     const double* __restrict__ t = tiles[buf];
     const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
+    double f[9];
     for (int c = 0; c < cnt; ++c) {
-      const double* __restrict__ u = t + kCpFieldTile + c * kCouplingWeights;  // wave-uniform
-      const double lxr = t[o_lxr + c * 8], lxh = t[o_lxh + c * 8], lpsi = t[o_lpsi + c * 8], lp = t[o_lp + c * 8];
-      const double rxr = t[o_rxr + c * 8], rxh = t[o_rxh + c * 8], rtpv = t[o_rtp + c * 8], rtnv = t[o_rtn + c * 8],
-                   rrho = t[o_rrho + c * 8];
+      fetch(t, c, f);
+      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;  // wave-uniform
+      const double lxr = f[0], lxh = f[1], lpsi = f[2], lp = f[3];
+      const double rxr = f[4], rxh = f[5], rtpv = f[6], rtnv = f[7], rrho = f[8];
       const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
       const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
       const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
@@ -356,20 +356,26 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
       r_zero += mrot * (mrot * val + val_t);
       const double sig = rfreq - mrot;
       const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
-      // the six divisions by r share one refined reciprocal (shared_div.hpp: same bits as six real divisions)
-      double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
-                      lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
+      const SharedDenominator den = shared_div_prepare(x);
+      double t0, t1, t2, t3, t4, t5;
       if (no_q2) {
-        // dv[1], dv[3], dv[4], dv[5] carry a factor q2 or q2_hrd that is zero for every lane of this wave: they are
-        // +-0 (or NaN) and dividing them by the radius (finite, > 0 from the second grid point on) returns them
-        // unchanged, so only two quotients are left.  (Without this the zero numerators fail the exponent test of
-        // the shared reciprocal and the whole wave takes six full divisions per point.)
-        shared_div2(dv[0], dv[2], shared_div_prepare(x));
+        // the four terms with a factor q2 or q2_hrd are +-0 (or NaN) for every lane of this wave and dividing them by the
+        // radius returns them unchanged: two quotients are left
+        t0 = rho * lpsi * rxr * adtea;
+        t2 = lp * rxr * adtea;
+        shared_div2(t0, t2, den);
+        t1 = rho * lpsi * q2 * rxr * adteb;
+        t3 = lp * q2 * rxr * adteb;
+        t4 = lp * q2_hrd * rxh * teb;
+        t5 = q2_hrd * rho * lpsi * rxh * teb;
       } else {
-        shared_div6(dv, shared_div_prepare(x));
+        double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
+                        lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
+        shared_div6(dv, den);
+        t0 = dv[0]; t1 = dv[1]; t2 = dv[2]; t3 = dv[3]; t4 = dv[4]; t5 = dv[5];
       }
       l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
-                             lpsi * rrho * tea - dv[0] + lpsi * q2 * rrho * teb - dv[1] - dv[2] - dv[3] - dv[4] + dv[5]);
+                             lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
       finite = finite && isfinite(l_zero);
     }
     buf ^= 1;
@@ -381,6 +387,7 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
     if (!finite) atomicOr(a.flags, 1);
   }
 }
+
 
 __global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) { coupling_body(a, blockIdx.x, blockIdx.y); }
 
