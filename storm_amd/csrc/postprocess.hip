@@ -273,12 +273,15 @@ typedef __attribute__((address_space(1))) const void* cp_glb_ptr;
 // one point sit in 8 consecutive doubles (conflict-free reads, each shared by 8 lanes).  One DMA instruction
 // moves 256 B = 4 points x 8 modes; lane -> (point, mode, half of the double).
 // `lrow` / `rrow`: the fields row of the left / right mode this LANE stages (see coupling_body).
+// NULL_TILE: only the four planes the shortcut of coupling_body reads (left psi, p; right xi_r, rho).
+template <bool NULL_TILE>
 PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t rc0, double* tile, int lane) {
   const size_t np = a.n_pts;
   const int pt_in = lane >> 4, word = lane & 1;
   constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
 #pragma unroll
   for (int pl = 0; pl < 9; ++pl) {
+    if (NULL_TILE && !(pl == 2 || pl == 3 || pl == 4 || pl == 8)) continue;
     const double* row = a.fields + ((pl < 4 ? lrow : rrow) * kPostFields + kPlanes[pl]) * np;
 #pragma unroll
     for (int h = 0; h < kCpChunk / 4; ++h) {
@@ -325,12 +328,49 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
 #pragma unroll
     for (int pl = 0; pl < 9; ++pl) f[pl] = t[pl * kCpPlane + c * 8 + (pl < 4 ? tl : tr)];
   };
-  coupling_stage(a, lrow, rrow, 1, tiles[0], lane);
+  // Degrees more than 2 apart: all ten factors are zero.  With finite operands of moderate size every product that
+  // contains one of them is +-0, five of the six sums stay +0.0 and what is left of l_zero's term is
+  // trap r^2 ((psi_l rho'_r tea - rho psi_l xi_r adtea / r) - p_l xi_r adtea / r): adding or subtracting a zero never
+  // changes a non-zero partial sum, and an accumulator that starts at +0.0 never becomes -0.0, so the signs of the
+  // dropped zeros cannot reach the result.  "Moderate" (the `tame` flags: |v| < 2^200, so no dropped product overflows
+  // into inf * 0 = NaN) is checked per mode by coupling_tame_kernel and for the weights on the host; anything else takes
+  // the full expression below.
+  const bool all_zero = q2 == 0.0 && q2_hrd == 0.0 && q2_hld == 0.0 && q2_h == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 &&
+                        q_ht_p == 0.0 && q_ht_n == 0.0 && ipr == 0.0 && iph == 0.0;
+  if (a.tame != nullptr && a.weights_tame && __all(all_zero && a.tame[lm] != 0 && a.tame[rm] != 0)) {
+    coupling_stage<true>(a, lrow, rrow, 1, tiles[0], lane);
+    int buf = 0;
+    for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (rc0 + kCpChunk < np) coupling_stage<true>(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
+      const double* __restrict__ t = tiles[buf];
+      const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
+      for (int c = 0; c < cnt; ++c) {
+        const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;
+        const double lpsi = t[2 * kCpPlane + c * 8 + tl], lp = t[3 * kCpPlane + c * 8 + tl];
+        const double rxr = t[4 * kCpPlane + c * 8 + tr], rrho = t[8 * kCpPlane + c * 8 + tr];
+        const double adtea = u[CW_ADTEA];
+        double t0 = u[CW_RHO] * lpsi * rxr * adtea, t2 = lp * rxr * adtea;
+        shared_div2(t0, t2, shared_div_prepare(u[CW_X]));
+        l_zero += u[CW_TR2] * (lpsi * rrho * u[CW_TEA] - t0 - t2);
+      }
+      buf ^= 1;
+    }
+    if (live) {
+      const size_t at = lm + rm * M, mm = M * M;
+      a.out[0 * mm + at] = 0.0; a.out[1 * mm + at] = 0.0; a.out[2 * mm + at] = 0.0;
+      a.out[3 * mm + at] = 0.0; a.out[4 * mm + at] = 0.0; a.out[5 * mm + at] = l_zero;
+      if (!isfinite(l_zero)) atomicOr(a.flags, 1);  // non-finite is absorbing under +=: the last value tells
+    }
+    return;
+  }
+  coupling_stage<false>(a, lrow, rrow, 1, tiles[0], lane);
   int buf = 0;
   for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (rc0 + kCpChunk < np) coupling_stage(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
+    if (rc0 + kCpChunk < np) coupling_stage<false>(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
     const double* __restrict__ t = tiles[buf];
     const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
     double f[9];
@@ -389,6 +429,41 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
 }
 
 
+// tame[k] = 1 if the frequency of mode k and every value of the seven field planes the integrals read are finite and
+// smaller than 2^200 in magnitude (exponent test on the high words).  One workgroup per mode.
+constexpr unsigned kTameLimit = unsigned(1023 + 200) << 20;
+PDEV void coupling_tame_body(const CouplingArgs& a, size_t k) {
+  __shared__ unsigned part[4];
+  const size_t row = a.rows ? (size_t)a.rows[k] : k;
+  constexpr int kPlanes[7] = {XI_R, XI_H, PSI, PRS, XI_TP, XI_TN, RHO};
+  unsigned hi = unsigned(__double2hiint(a.freq[k])) & 0x7fffffffu;
+  for (int pl = 0; pl < 7; ++pl) {
+    const double* __restrict__ v = a.fields + (row * kPostFields + kPlanes[pl]) * a.n_pts;
+    for (size_t i = threadIdx.x; i < a.n_pts; i += 256) {
+      const unsigned w = unsigned(__double2hiint(v[i])) & 0x7fffffffu;
+      hi = w > hi ? w : hi;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)hi, off);
+    hi = o > hi ? o : hi;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) hi = part[w] > hi ? part[w] : hi;
+    a.tame[k] = hi < kTameLimit ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void coupling_tame_kernel(CouplingArgs a) { coupling_tame_body(a, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void coupling_tame_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.y];
+  if (a.tame == nullptr || blockIdx.x >= a.n_modes) return;
+  coupling_tame_body(a, blockIdx.x);
+}
+
 __global__ __launch_bounds__(64, 2) void coupling_kernel(CouplingArgs a) { coupling_body(a, blockIdx.x, blockIdx.y); }
 
 // blockIdx.z = problem; the grid covers the largest one, tiles past a problem's own size leave at once
@@ -437,10 +512,16 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
   return hipGetLastError();
 }
 
-hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream) {
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream,
+                                 bool with_tame) {
   if (n_problems == 0 || max_modes == 0) return hipSuccess;
   const unsigned tiles = (unsigned)((max_modes + 7) / 8);
   if (tiles > 65535 || n_problems > 65535) return hipErrorInvalidValue;
+  if (with_tame) {
+    coupling_tame_batch_kernel<<<dim3((unsigned)max_modes, (unsigned)n_problems, 1), 256, 0, stream>>>(table);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   coupling_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
   return hipGetLastError();
 }
@@ -450,6 +531,11 @@ hipError_t launch_coupling(const CouplingArgs& a) {
   if (a.n_pts < 2) return hipErrorInvalidValue;
   const unsigned tiles = (unsigned)((a.n_modes + 7) / 8);
   if (tiles > 65535) return hipErrorInvalidValue;
+  if (a.tame) {
+    coupling_tame_kernel<<<(unsigned)a.n_modes, 256, 0, a.stream>>>(a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   coupling_kernel<<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
   return hipGetLastError();
 }

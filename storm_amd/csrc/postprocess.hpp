@@ -93,11 +93,18 @@ struct CouplingArgs {
   double* out;             // device [kCouplingMatrices][n_modes*n_modes], (left, right) at left + right*n_modes
   int* flags;              // device; bit 0 set if a term was not finite (the reference asserts)
   hipStream_t stream;
+  // Shortcut for tiles whose ten Gaunt factors are all zero (degrees more than 2 apart): see coupling_body.  `tame`:
+  // device [n_modes] scratch the launch fills (1 = every field value and the frequency of the mode are finite and
+  // below 2^200 in magnitude), nullptr = never take the shortcut; weights_tame: the same property of `weights` (host).
+  int* tame = nullptr;
+  int weights_tame = 0;
 };
 hipError_t launch_coupling(const CouplingArgs& args);
 // Several coupling problems in one launch: blockIdx.z picks table[z] (device array; args.stream is ignored).
 // max_modes = the largest n_modes in the table.
-hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream);
+// with_tame: some entry has a `tame` array to fill first.
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream,
+                                 bool with_tame = false);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.

@@ -1068,6 +1068,24 @@ size_t coupling_consts(size_t n, const uint64_t* ell, int64_t m, int* ell_index,
   return ne;
 }
 
+// The kernel's shortcut for tiles whose Gaunt factors are all zero (postprocess.hip, coupling_body) needs finite
+// operands of moderate size: the weights are checked here, the modes on the device.
+bool coupling_weights_tame(const double* w, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!(std::fabs(w[i]) < 0x1p200)) return false;
+  return true;
+}
+
+// Is there a pair of degrees whose ten factors are all zero (degrees more than 2 apart)?
+bool coupling_has_null_pair(const std::vector<double>& consts) {
+  for (size_t at = 0; at + kCouplingConsts <= consts.size(); at += kCouplingConsts) {
+    bool all_zero = true;
+    for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && consts[at + k] == 0.0;
+    if (all_zero) return true;
+  }
+  return false;
+}
+
 void check_metric(const storm_metric_desc* metric) {
   if (!metric) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
   const double* ms[6] = {metric->alpha, metric->dalpha, metric->ddalpha, metric->beta, metric->dbeta, metric->ddbeta};
@@ -1102,7 +1120,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     p->d_consts.reserve(consts.size(), p->stream);
     p->d_ell_index.reserve(n, p->stream);
     p->d_out.reserve(size_t(kCouplingMatrices) * n * n, p->stream);
-    p->d_cflags.reserve(1, p->stream);
+    p->d_cflags.reserve(1 + n, p->stream);  // [0]: non-finite flag, [1..]: per-mode "tame" flags (kernel scratch)
     hipStream_t st = post_stream(p);
     provide_fields(p->d_fields.p, st);
     hip_check(hipMemcpyAsync(p->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
@@ -1114,6 +1132,10 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
     a.rows = nullptr; a.stream = st;
+    if (coupling_has_null_pair(consts)) {
+      a.tame = p->d_cflags.p + 1;
+      a.weights_tame = coupling_weights_tame(w.data(), np * kCouplingWeights) ? 1 : 0;
+    }
     if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
     if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
     hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
@@ -1909,7 +1931,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     q->d_cp.reserve(in_elems + out_total, st);
     q->d_cp_idx.reserve(total, st);
     q->d_cp_ell.reserve(total, st);
-    q->d_cp_flags.reserve(1, st);
+    q->d_cp_flags.reserve(1 + total, st);  // [0]: non-finite flag, [1..]: per-mode "tame" flags (kernel scratch)
     q->d_cp_table.reserve(n_problems, st);
     double* dw = q->d_cp.p;
     double* dc = dw + n_problems * w_elems;
@@ -1917,6 +1939,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     double* dout = q->d_cp.p + in_elems;
     std::vector<CouplingArgs> table(n_problems);
     size_t out_at = 0;
+    bool with_tame = false;
     for (size_t j = 0; j < n_problems; ++j) {
       const size_t n = offsets[j + 1] - offsets[j];
       CouplingArgs& a = table[j];
@@ -1924,6 +1947,11 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
       a.freq = df + offsets[j]; a.ell_index = q->d_cp_ell.p + offsets[j];
       a.consts = dc + c_off[j]; a.n_ell = int(n_ell[j]); a.weights = dw + j * w_elems;
       a.out = dout + out_at; a.flags = q->d_cp_flags.p; a.stream = st;
+      if (n && coupling_has_null_pair(consts[j])) {
+        a.tame = q->d_cp_flags.p + 1 + offsets[j];
+        a.weights_tame = coupling_weights_tame(hw + j * w_elems, np * kCouplingWeights) ? 1 : 0;
+        with_tame = true;
+      }
       out_at += size_t(kCouplingMatrices) * n * n;
     }
     hip_check(hipMemcpyAsync(q->d_cp.p, q->h_cp.p, in_elems * sizeof(double), hipMemcpyHostToDevice, st), "coupling inputs H2D");
@@ -1931,7 +1959,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     hip_check(hipMemcpyAsync(q->d_cp_ell.p, ell_index.data(), total * sizeof(int), hipMemcpyHostToDevice, st), "ell H2D");
     hip_check(hipMemcpyAsync(q->d_cp_table.p, table.data(), n_problems * sizeof(CouplingArgs), hipMemcpyHostToDevice, st), "table H2D");
     hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
-    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, st), "coupling launch");
+    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, st, with_tame), "coupling launch");
     q->stats.launches += 1;
     // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the
     // results only after the stream has been synchronised)

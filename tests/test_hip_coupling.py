@@ -192,3 +192,58 @@ def test_config5_deformed_star_pipeline(oracle, golden_dir):
     assert w.size == n
     shift = np.abs(w - np.sort(freqs)) / np.sort(freqs)
     assert shift.max() < 0.05 and np.median(shift) < 5e-3      # O(rot^2) = 1e-2 at most a few per cent
+
+
+def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
+    """Degrees more than 2 apart have all ten Gaunt factors zero and the kernel walks such 8 x 8 tiles with the three
+    terms of l_zero that carry no factor (reference src/perturbed.rs:215-236; postprocess.hip, coupling_body).  Same bits
+    as the full expression of the oracle: for whole tiles (16 modes of ell = 1 next to 16 of ell = 5), for modes whose
+    values are too large for the shortcut's argument (it must fall back) and for a zero metric (every remaining term
+    is a signed zero)."""
+    import storm_amd
+    model = oracle_models("tams")
+    model.set_rotation_constant(0.08)
+    grid = model.field("r_coord")
+    metric = model.perturb_structure(0.08)
+    parts = [modes_of(oracle, model, grid, (ell,), 1, 1.0, 25.0, 300) for ell in (1, 5, 3)]
+    n_each = min(p[1].size for p in parts)
+    assert n_each >= 16
+    ell = np.concatenate([p[0][:16] for p in parts])
+    freq = np.concatenate([p[1][:16] for p in parts])
+    fields = np.ascontiguousarray(np.concatenate([p[2][:16] for p in parts]))
+    post = hip_post(model)
+
+    def check(fields, metric):
+        ref, _ = model.coupling_matrices(ell, freq, fields, 1, metric, threads=16)
+        got = post.coupling_matrices(ell, freq, fields, 1, metric)
+        for k in storm_amd.COUPLING_MATRICES:
+            assert same_bits(ref[k], got[k]), k
+        return got
+
+    got = check(fields, metric)
+    far = np.abs(ell[:, None].astype(int) - ell[None, :].astype(int)) > 2
+    assert far.sum() == 2 * 16 * 16
+    for k in ("d_squared", "d_linear", "d_zero", "r_linear", "r_zero"):
+        assert np.all(got[k][far] == 0.0) and not np.any(np.signbit(got[k][far])), k
+    assert np.all(got["l_zero"][far] != 0.0)        # the terms without a Gaunt factor
+    # one mode of ell = 5 scaled by 2^300 (exact): products of two such values overflow, the shortcut's argument does not
+    # hold for the tiles of that mode and they take the full expression -- whatever it gives, the bits are the oracle's
+    big = fields.copy()
+    big[16 + 3] *= 2.0 ** 300
+    try:
+        model.coupling_matrices(ell, freq, big, 1, metric, threads=16)
+        oracle_asserts = False
+    except RuntimeError:
+        oracle_asserts = True     # the full expression runs into inf * 0 = NaN: the reference asserts
+    if oracle_asserts:
+        with pytest.raises(storm_amd.StormError, match="finite"):
+            post.coupling_matrices(ell, freq, big, 1, metric)
+    else:
+        check(big, metric)
+    # moderately large values (2^150) stay inside the argument: shortcut and oracle agree
+    mid = fields.copy()
+    mid[16 + 3] *= 2.0 ** 150
+    check(mid, metric)
+    zero = {k: np.zeros(grid.size) for k in ("alpha", "dalpha", "ddalpha", "beta", "dbeta", "ddbeta")}
+    got = check(fields, zero)
+    assert np.all(got["l_zero"][far] == 0.0) and not np.any(np.signbit(got["l_zero"][far]))
