@@ -14,6 +14,7 @@
 #include "postprocess.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include "shared_div.hpp"
 
 #define PDEV __device__ __forceinline__
@@ -337,7 +338,8 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   // the full expression below.
   const bool all_zero = q2 == 0.0 && q2_hrd == 0.0 && q2_hld == 0.0 && q2_h == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 &&
                         q_ht_p == 0.0 && q_ht_n == 0.0 && ipr == 0.0 && iph == 0.0;
-  if (a.tame != nullptr && a.weights_tame && __all(all_zero && a.tame[lm] != 0 && a.tame[rm] != 0)) {
+  const bool tame_tile = a.tame != nullptr && a.weights_tame && __all(a.tame[lm] != 0 && a.tame[rm] != 0);
+  if (tame_tile && __all(all_zero)) {
     coupling_stage<true>(a, lrow, rrow, 1, tiles[0], lane);
     int buf = 0;
     for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {
@@ -365,61 +367,85 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
     }
     return;
   }
-  coupling_stage<false>(a, lrow, rrow, 1, tiles[0], lane);
-  int buf = 0;
-  for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (rc0 + kCpChunk < np) coupling_stage<false>(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
-    const double* __restrict__ t = tiles[buf];
-    const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
-    double f[9];
-    for (int c = 0; c < cnt; ++c) {
-      fetch(t, c, f);
-      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;  // wave-uniform
-      const double lxr = f[0], lxh = f[1], lpsi = f[2], lp = f[3];
-      const double rxr = f[4], rxh = f[5], rtpv = f[6], rtnv = f[7], rrho = f[8];
-      const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
-      const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
-      const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
-      double val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
-                                (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
-      finite = finite && isfinite(val);
-      d_squared += val;
-      d_linear += u[CW_C1] * val;
-      d_zero += u[CW_C2] * val;
-      val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
-      const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
-      finite = finite && isfinite(val) && isfinite(val_t);
-      const double mrot = u[CW_MROT];
-      r_linear += mrot * val + val_t;
-      r_zero += mrot * (mrot * val + val_t);
-      const double sig = rfreq - mrot;
-      const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
-      const SharedDenominator den = shared_div_prepare(x);
-      double t0, t1, t2, t3, t4, t5;
-      if (no_q2) {
-        // the four terms with a factor q2 or q2_hrd are +-0 (or NaN) for every lane of this wave and dividing them by the
-        // radius returns them unchanged: two quotients are left
-        t0 = rho * lpsi * rxr * adtea;
-        t2 = lp * rxr * adtea;
-        shared_div2(t0, t2, den);
-        t1 = rho * lpsi * q2 * rxr * adteb;
-        t3 = lp * q2 * rxr * adteb;
-        t4 = lp * q2_hrd * rxh * teb;
-        t5 = q2_hrd * rho * lpsi * rxh * teb;
-      } else {
-        double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
-                        lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
-        shared_div6(dv, den);
-        t0 = dv[0]; t1 = dv[1]; t2 = dv[2]; t3 = dv[3]; t4 = dv[4]; t5 = dv[5];
+  // Different degrees (src/perturbed.rs:134-146): the inner products and the four toroidal factors are zero.  By the
+  // same argument as above a tile of such pairs skips the products that contain them (about a quarter of the
+  // instructions); OFF_DIAG is that variant of the walk, the other one is the reference's expression term by term.
+  const bool off_diag = ipr == 0.0 && iph == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 && q_ht_p == 0.0 && q_ht_n == 0.0;
+  auto walk = [&](auto off_diag_tag) {
+    constexpr bool OFF_DIAG = decltype(off_diag_tag)::value;
+    coupling_stage<false>(a, lrow, rrow, 1, tiles[0], lane);
+    int buf = 0;
+    for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {  // src/perturbed.rs:148-261
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (rc0 + kCpChunk < np) coupling_stage<false>(a, lrow, rrow, rc0 + kCpChunk, tiles[buf ^ 1], lane);
+      const double* __restrict__ t = tiles[buf];
+      const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
+      double f[9];
+      for (int c = 0; c < cnt; ++c) {
+        fetch(t, c, f);
+        const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;  // wave-uniform
+        const double lxr = f[0], lxh = f[1], lpsi = f[2], lp = f[3];
+        const double rxr = f[4], rxh = f[5], rtpv = f[6], rtnv = f[7], rrho = f[8];
+        const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+        const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
+        double val;
+        if constexpr (OFF_DIAG)
+          val = u[CW_VOL] * (rr * 2.0 * q2 * u[CW_U3] + (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+        else
+          val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
+                             (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+        finite = finite && isfinite(val);
+        d_squared += val;
+        d_linear += u[CW_C1] * val;
+        d_zero += u[CW_C2] * val;
+        const double mrot = u[CW_MROT];
+        if constexpr (OFF_DIAG) {
+          val = u[CW_VOL2] * ((rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+          finite = finite && isfinite(val);
+          r_linear += mrot * val;
+          r_zero += mrot * (mrot * val);
+        } else {
+          const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
+          val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+          const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
+          finite = finite && isfinite(val) && isfinite(val_t);
+          r_linear += mrot * val + val_t;
+          r_zero += mrot * (mrot * val + val_t);
+        }
+        const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
+        const SharedDenominator den = shared_div_prepare(x);
+        double t0, t1, t2, t3, t4, t5;
+        if (no_q2) {
+          // the four terms with a factor q2 or q2_hrd are +-0 (or NaN) for every lane of this wave and dividing them by
+          // the radius returns them unchanged: two quotients are left
+          t0 = rho * lpsi * rxr * adtea;
+          t2 = lp * rxr * adtea;
+          shared_div2(t0, t2, den);
+          t1 = rho * lpsi * q2 * rxr * adteb;
+          t3 = lp * q2 * rxr * adteb;
+          t4 = lp * q2_hrd * rxh * teb;
+          t5 = q2_hrd * rho * lpsi * rxh * teb;
+        } else {
+          double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
+                          lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
+          shared_div6(dv, den);
+          t0 = dv[0]; t1 = dv[1]; t2 = dv[2]; t3 = dv[3]; t4 = dv[4]; t5 = dv[5];
+        }
+        if constexpr (OFF_DIAG) {
+          l_zero += u[CW_TR2] * (lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
+        } else {
+          const double sig = rfreq - mrot;
+          l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
+                                 lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
+        }
+        finite = finite && isfinite(l_zero);
       }
-      l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
-                             lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
-      finite = finite && isfinite(l_zero);
+      buf ^= 1;
     }
-    buf ^= 1;
-  }
+  };
+  if (tame_tile && __all(off_diag)) walk(std::true_type{});
+  else walk(std::false_type{});
   if (live) {
     const size_t at = lm + rm * M, mm = M * M;
     a.out[0 * mm + at] = d_squared; a.out[1 * mm + at] = d_linear; a.out[2 * mm + at] = d_zero;

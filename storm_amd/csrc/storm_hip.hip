@@ -1076,13 +1076,11 @@ bool coupling_weights_tame(const double* w, size_t n) {
   return true;
 }
 
-// Is there a pair of degrees whose ten factors are all zero (degrees more than 2 apart)?
-bool coupling_has_null_pair(const std::vector<double>& consts) {
-  for (size_t at = 0; at + kCouplingConsts <= consts.size(); at += kCouplingConsts) {
-    bool all_zero = true;
-    for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && consts[at + k] == 0.0;
-    if (all_zero) return true;
-  }
+// Is there a pair of degrees the kernel has a shorter walk for (different degrees: inner products and toroidal factors
+// are zero; more than 2 apart: all ten)?
+bool coupling_has_sparse_pair(const std::vector<double>& consts) {
+  for (size_t at = 0; at + kCouplingConsts <= consts.size(); at += kCouplingConsts)
+    if (consts[at + CQ_IPR] == 0.0 && consts[at + CQ_IPH] == 0.0) return true;
   return false;
 }
 
@@ -1132,7 +1130,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
     a.rows = nullptr; a.stream = st;
-    if (coupling_has_null_pair(consts)) {
+    if (coupling_has_sparse_pair(consts)) {
       a.tame = p->d_cflags.p + 1;
       a.weights_tame = coupling_weights_tame(w.data(), np * kCouplingWeights) ? 1 : 0;
     }
@@ -1947,7 +1945,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
       a.freq = df + offsets[j]; a.ell_index = q->d_cp_ell.p + offsets[j];
       a.consts = dc + c_off[j]; a.n_ell = int(n_ell[j]); a.weights = dw + j * w_elems;
       a.out = dout + out_at; a.flags = q->d_cp_flags.p; a.stream = st;
-      if (n && coupling_has_null_pair(consts[j])) {
+      if (n && coupling_has_sparse_pair(consts[j])) {
         a.tame = q->d_cp_flags.p + 1 + offsets[j];
         a.weights_tame = coupling_weights_tame(hw + j * w_elems, np * kCouplingWeights) ? 1 : 0;
         with_tame = true;
