@@ -160,11 +160,7 @@ def main():
             solvers[k].eigenvector(np.array([b["root"] for b in res]))
         return lo, res, inv
 
-    def one_step():
-        if pool is not None:
-            parts = list(pool.map(scan_one, range(len(solvers))))
-        else:
-            parts = [scan_one(k) for k in range(len(solvers))]
+    def finish_step(parts):
         modes_global = 0
         for lo, res, inv in parts:
             if world > 1:
@@ -173,6 +169,45 @@ def main():
             else:
                 modes_global += len(res)
         return modes_global
+
+    def one_step():
+        if pool is not None:
+            parts = list(pool.map(scan_one, range(len(solvers))))
+        else:
+            parts = [scan_one(k) for k in range(len(solvers))]
+        return finish_step(parts)
+
+    def run_steps(steps):
+        """`steps` passes = steps x 6 scans.  Each of the six handles runs its scans back to back on its own host thread
+        and stream, so the latency-bound end of one pass (refinement rounds, eigenvectors of the last scans) overlaps
+        the step-matrix kernels of the next pass instead of leaving the GPU idle between passes; the main thread
+        completes the passes in order (for N > 1: the gathers of pass s while the workers are already in pass s + 1)."""
+        if pool is None:
+            modes = 0
+            for _ in range(steps):
+                modes = one_step()
+            return modes
+        import queue
+        done = [queue.Queue() for _ in solvers]
+
+        def chain(k):
+            try:
+                for _ in range(steps):
+                    done[k].put(scan_one(k))
+            except BaseException as e:  # noqa: BLE001 -- handed to the main thread
+                done[k].put(e)
+
+        futures = [pool.submit(chain, k) for k in range(len(solvers))]
+        modes = 0
+        for _ in range(steps):
+            parts = [q.get() for q in done]
+            for part in parts:
+                if isinstance(part, BaseException):
+                    raise part
+            modes = finish_step(parts)
+        for f in futures:
+            f.result()
+        return modes
 
     def sync():
         if world > 1:
@@ -190,9 +225,7 @@ def main():
             s.kernel_times(reset=True)
         sync()
         t0 = time.perf_counter()
-        modes = 0
-        for _ in range(steps):
-            modes = one_step()
+        modes = run_steps(steps)
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -367,7 +400,8 @@ def main():
             "config": {"workload": "BASELINE config 2: test-model-tams (6199 intervals), ell=1..3, m=0, Magnus6 + "
                                    "Colloc8, linspace(1,25,10^4 per GPU), precision 1e-8, + eigenvector per mode",
                        "n_freq_total": n_total, "n_int": n_int, "scans": len(CASES),
-                       "parallelism": f"freq-slice x{world}", "concurrent_scans": args.threads if args.threads > 1 else 1},
+                       "parallelism": f"freq-slice x{world}", "concurrent_scans": args.threads if args.threads > 1 else 1,
+                       "passes_back_to_back_per_handle": args.threads > 1},
             "modes_per_s": modes * args.steps / elapsed if False else (eigs / elapsed),
             "modes_per_step": modes, "det_evals": det_evals, "refine_evals": refine,
             "arithmetic": args.arithmetic, "kernels": kernel_summary, "roofline": roofline,
