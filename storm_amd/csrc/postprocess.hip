@@ -354,7 +354,7 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
         const double rxr = t[4 * kCpPlane + c * 8 + tr], rrho = t[8 * kCpPlane + c * 8 + tr];
         const double adtea = u[CW_ADTEA];
         double t0 = u[CW_RHO] * lpsi * rxr * adtea, t2 = lp * rxr * adtea;
-        shared_div2(t0, t2, shared_div_prepare(u[CW_X]));
+        shared_div2(t0, t2, SharedDenominator{u[CW_X], u[CW_RX], shared_div_moderate(u[CW_X])});
         l_zero += u[CW_TR2] * (lpsi * rrho * u[CW_TEA] - t0 - t2);
       }
       buf ^= 1;
@@ -414,7 +414,7 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
           r_zero += mrot * (mrot * val + val_t);
         }
         const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
-        const SharedDenominator den = shared_div_prepare(x);
+        const SharedDenominator den{x, u[CW_RX], shared_div_moderate(x)};  // reciprocal: coupling_recip_kernel
         double t0, t1, t2, t3, t4, t5;
         if (no_q2) {
           // the four terms with a factor q2 or q2_hrd are +-0 (or NaN) for every lane of this wave and dividing them by
@@ -454,6 +454,21 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   }
 }
 
+
+// Column CW_RX of the weights: the refined reciprocal of the radius every division of a point shares (shared_div.hpp),
+// computed once per point here instead of once per (tile, point) in the walk -- the same instructions on the same
+// input, so the same bits.
+PDEV void coupling_recip_body(const CouplingArgs& a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_pts) a.weights[i * kCouplingWeights + CW_RX] = shared_div_prepare(a.weights[i * kCouplingWeights + CW_X]).r;
+}
+
+__global__ __launch_bounds__(256) void coupling_recip_kernel(CouplingArgs a) { coupling_recip_body(a); }
+
+__global__ __launch_bounds__(256) void coupling_recip_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.y];
+  if (a.n_modes) coupling_recip_body(a);
+}
 
 // tame[k] = 1 if the frequency of mode k and every value of the seven field planes the integrals read are finite and
 // smaller than 2^200 in magnitude (exponent test on the high words).  One workgroup per mode.
@@ -538,13 +553,18 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
   return hipGetLastError();
 }
 
-hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream,
-                                 bool with_tame) {
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
+                                 hipStream_t stream, bool with_tame) {
   if (n_problems == 0 || max_modes == 0) return hipSuccess;
   const unsigned tiles = (unsigned)((max_modes + 7) / 8);
   if (tiles > 65535 || n_problems > 65535) return hipErrorInvalidValue;
   if (with_tame) {
     coupling_tame_batch_kernel<<<dim3((unsigned)max_modes, (unsigned)n_problems, 1), 256, 0, stream>>>(table);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  {
+    coupling_recip_batch_kernel<<<dim3((unsigned)((n_pts + 255) / 256), (unsigned)n_problems, 1), 256, 0, stream>>>(table);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -559,6 +579,11 @@ hipError_t launch_coupling(const CouplingArgs& a) {
   if (tiles > 65535) return hipErrorInvalidValue;
   if (a.tame) {
     coupling_tame_kernel<<<(unsigned)a.n_modes, 256, 0, a.stream>>>(a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  coupling_recip_kernel<<<(unsigned)((a.n_pts + 255) / 256), 256, 0, a.stream>>>(a);
+  {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -76,7 +76,8 @@ enum CouplingWeight : int {
   CW_U4,        // 1 + 2 eps_a + a d eps_a
   CW_U5,        // 2 eps_b + a d eps_b
   CW_EB, CW_TEA, CW_ADTEA, CW_TEB, CW_ADTEB,
-  kCouplingWeights = 20  // padded: rows of 160 B
+  CW_RX,        // refined reciprocal of x (shared_div.hpp), filled on the device by the launch
+  kCouplingWeights = 20  // rows of 160 B
 };
 // Per-(ell_left, ell_right) Gaunt factors (src/perturbed.rs:126-146).
 enum CouplingConst : int { CQ_Q2 = 0, CQ_Q2_HRD, CQ_Q2_HLD, CQ_Q2_H, CQ_RT_P, CQ_RT_N, CQ_HT_P, CQ_HT_N, CQ_IPR, CQ_IPH, kCouplingConsts };
@@ -89,7 +90,7 @@ struct CouplingArgs {
   const int* ell_index;    // device [n_modes], index into the distinct-ell list
   const double* consts;    // device [n_ell][n_ell][kCouplingConsts]
   int n_ell;
-  const double* weights;   // device [n_pts][kCouplingWeights]
+  double* weights;         // device [n_pts][kCouplingWeights]; the launch fills column CW_RX
   double* out;             // device [kCouplingMatrices][n_modes*n_modes], (left, right) at left + right*n_modes
   int* flags;              // device; bit 0 set if a term was not finite (the reference asserts)
   hipStream_t stream;
@@ -102,9 +103,9 @@ struct CouplingArgs {
 hipError_t launch_coupling(const CouplingArgs& args);
 // Several coupling problems in one launch: blockIdx.z picks table[z] (device array; args.stream is ignored).
 // max_modes = the largest n_modes in the table.
-// with_tame: some entry has a `tame` array to fill first.
-hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, hipStream_t stream,
-                                 bool with_tame = false);
+// n_pts = the (common) grid size of the entries; with_tame: some entry has a `tame` array to fill first.
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
+                                 hipStream_t stream, bool with_tame = false);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.

@@ -1005,7 +1005,8 @@ int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const do
 
 namespace {
 // Per-point weights of the coupling integrals: the mode-independent sub-expressions of src/perturbed.rs:88-108,157-252.
-// `w`: (n_pts + 16) * kCouplingWeights doubles (one chunk of zero padding: the kernel stages 8 points at a time).
+// `w`: (n_pts + 16) * kCouplingWeights doubles (16 rows of zero padding, never read since the kernel takes the weights
+// through scalar loads; column CW_RX is left zero here and filled on the device).
 void coupling_weights(const storm_postproc* p, int64_t m, const storm_metric_desc* metric, double* w) {
   const size_t np = p->model.n_pts;
   std::memset(w, 0, (np + 16) * kCouplingWeights * sizeof(double));
@@ -1957,7 +1958,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     hip_check(hipMemcpyAsync(q->d_cp_ell.p, ell_index.data(), total * sizeof(int), hipMemcpyHostToDevice, st), "ell H2D");
     hip_check(hipMemcpyAsync(q->d_cp_table.p, table.data(), n_problems * sizeof(CouplingArgs), hipMemcpyHostToDevice, st), "table H2D");
     hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
-    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, st, with_tame), "coupling launch");
+    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, np, st, with_tame), "coupling launch");
     q->stats.launches += 1;
     // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the
     // results only after the stream has been synchronised)
