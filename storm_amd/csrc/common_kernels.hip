@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void eigen_forward_kernel(SystemDev s0, const d
   const int lane = threadIdx.x;
   const int j = lane;          // lanes 0..7 carry the band; the others idle along (their values are never used)
   const size_t m = blockIdx.x;  // one wave per mode
-  const SystemDev s = table ? table[sys_index[m]] : s0;  // several systems per launch: see LaunchArgs in types.hpp
+  const SystemDev s = pick_system(s0, table, sys_index, m);  // several systems per launch: see LaunchArgs in types.hpp
   const double f = freq[m];
   const size_t n_int = s.n_int;
   const size_t ustride = n_int * 22 + 6;

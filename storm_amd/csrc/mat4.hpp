@@ -175,17 +175,20 @@ SDEV M4 m4_exp(M4 a) {
   const M4 a2 = m4_mul(a, a);
   const M4 a3 = m4_mul(a2, a);
   const M4 a6 = m4_mul(a3, a3);
-  M4 b[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
+  // b_i = T[i][0] I + T[i][1] A + T[i][2] A^2 + T[i][3] A^3 + T[i][4] A^6, formed where it is consumed (five of them at
+  // once are 160 registers)
+  auto combo = [&](int i) {
+    M4 b;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const double id = ((e % 5) == 0) ? 1.0 : 0.0;
-      b[i].v[e] = (((id * T[i][0] + a.v[e] * T[i][1]) + a2.v[e] * T[i][2]) + a3.v[e] * T[i][3]) + a6.v[e] * T[i][4];
+      b.v[e] = (((id * T[i][0] + a.v[e] * T[i][1]) + a2.v[e] * T[i][2]) + a3.v[e] * T[i][3]) + a6.v[e] * T[i][4];
     }
-  }
-  const M4 a9 = m4_add(m4_mul(b[0], b[4]), b[3]);
-  M4 r = m4_add(b[1], m4_mul(m4_add(b[2], a9), a9));
+    return b;
+  };
+  const M4 a9 = m4_add(m4_mul(combo(0), combo(4)), combo(3));
+  const M4 p9 = m4_mul(m4_add(combo(2), a9), a9);
+  M4 r = m4_add(combo(1), p9);
   for (int i = 0; i < exponent; ++i) r = m4_mul(r, r);
   return r;
 }

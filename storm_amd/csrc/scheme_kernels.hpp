@@ -143,7 +143,7 @@ SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
 // Magnus 2/4/6 need just over 256 registers when left alone; capping them at 256 buys a second wave
 // per SIMD (better issue utilisation, phase-B latency hidden behind the other wave's phase A).
 __host__ __device__ constexpr int hex_min_waves(int scheme) {
-  return (scheme == kMagnus2 || scheme == kMagnus4 || scheme == kMagnus6) ? 2 : 1;
+  return scheme == kMagnus2 ? 2 : 1;
 }
 
 // Coefficient staging for det_hex: the 13*P plane rows of the NEXT round (LPF intervals per row) are
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   const int c = e >> 2;
   const size_t t = (size_t)blockIdx.x * kFreqs + g;
   // the wave's system: its own when several systems share the launch (wave-uniform, read through the scalar unit)
-  const SystemDev s = table ? table[sys_index[(size_t)blockIdx.x * kFreqs]] : s0;
+  const SystemDev s = pick_system(s0, table, sys_index, (size_t)blockIdx.x * kFreqs);
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s0, const do
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t fi = blockIdx.y;
   if (fi >= n) return;
-  const SystemDev s = table ? table[sys_index[fi]] : s0;
+  const SystemDev s = pick_system(s0, table, sys_index, fi);
   const double f = freq[fi];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   if (i >= s.n_int) return;

@@ -40,6 +40,24 @@ struct SystemDev {
   double rotm_uniform;  // value of every m*rot entry when they are all bitwise equal
 };
 
+// The system of a wave when several systems share a launch: table[sys_index[at]] with a wave-uniform `at`, read through
+// the constant address space so that the 80 bytes arrive by scalar loads and stay in SGPRs like the kernel argument
+// `s0` does.  (A plain `table ? table[...] : s0` went through vector loads and selects and kept the struct in VGPRs:
+// +28 to +78 registers per kernel, one wave per SIMD less for colloc2 and colloc6.)
+__device__ __forceinline__ SystemDev pick_system(const SystemDev& s0, const SystemDev* table, const int* sys_index, size_t at) {
+  if (table == nullptr) return s0;
+  typedef const int __attribute__((address_space(4))) * c_int_ptr;
+  typedef const unsigned long long __attribute__((address_space(4))) * c_u64_ptr;
+  const int si = ((c_int_ptr)sys_index)[at];
+  const c_u64_ptr src = (c_u64_ptr)(table + si);
+  unsigned long long w[sizeof(SystemDev) / 8];
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(SystemDev) / 8; ++k) w[k] = src[k];
+  SystemDev s;
+  __builtin_memcpy(&s, w, sizeof(SystemDev));
+  return s;
+}
+
 struct LaunchArgs {
   SystemDev sys;
   const double* freq;  // device
