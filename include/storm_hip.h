@@ -275,6 +275,9 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16/32-lanes-per-frequency fused kernel
  *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default) the one whose wave count packs the
  *                GPU's wave slots better for this batch, 16, or 32
+ *   "hex_rounds": the path-4 kernel sends a batch that is larger than the GPU's wave slots in pieces of this many
+ *                 wave rounds (default 1), so that kernels of other handles get dispatched between the pieces
+ *                 instead of after the whole batch; 0 = one launch
  *   "eigen_layout": eigenvector kernels: 0 (default) one wave per mode below 1920 modes per launch and one lane per
  *                   mode from there on, 1 always wave per mode, 2 always lane per mode (same bits either way)
  *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
@@ -283,7 +286,7 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 
-/* Counters and options of a sweep ("arithmetic", "hex_lanes", "eigen_layout", "steps_bytes_max" as below; the
+/* Counters and options of a sweep ("arithmetic", "hex_lanes", "hex_rounds", "eigen_layout", "steps_bytes_max" as below; the
  * staging cap defaults to 16 GiB for a sweep). */
 int storm_sweep_stats(storm_sweep* sweep, storm_stats* out, int reset);
 int storm_sweep_set_option(storm_sweep* sweep, const char* key, int64_t value);

@@ -267,12 +267,16 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   }
 }
 
+// One wave per workgroup: a workgroup of four waves needs room on all four SIMDs of a CU at once, which it does not
+// find for tens of milliseconds while another handle's det_hex<colloc8> waves (one per SIMD, the whole register file)
+// are in flight (kernel trace of bench.py: a 0.5 ms refinement launch took 35 ms).
+constexpr int kBuildBlock = 64;
 template <int SCHEME, bool ELL0, bool UNIFORM>
-__global__ __launch_bounds__(256) void build_steps_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
+__global__ __launch_bounds__(kBuildBlock) void build_steps_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
                                                           double* __restrict__ steps, int* __restrict__ flags,
                                                           const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
-  // grid.x covers intervals in tiles of 256, grid.y = frequency
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // grid.x covers intervals in tiles of kBuildBlock, grid.y = frequency
+  const size_t i = (size_t)blockIdx.x * kBuildBlock + threadIdx.x;
   const size_t fi = blockIdx.y;
   if (fi >= n) return;
   const SystemDev s = pick_system(s0, table, sys_index, fi);

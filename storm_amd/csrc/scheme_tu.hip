@@ -6,6 +6,8 @@
 #error "compile with -DSTORM_SCHEME=<0..7>"
 #endif
 
+#include <algorithm>
+
 namespace STORM_NS {
 using namespace storm;
 
@@ -45,11 +47,31 @@ static double hex_cost(size_t n, size_t n_int) {
   const size_t waves = (n * LPF + 63) / 64, slots = hex_wave_slots<ELL0, UNIFORM, LPF>();
   return double((waves + slots - 1) / slots) * double((n_int + LPF - 1) / LPF) * (kStepFlops[STORM_SCHEME] + 20.0 * LPF);
 }
+// A batch of more waves than the GPU holds goes out in pieces of whole wave rounds.  All waves of a piece end together
+// (equal work), and between two pieces the dispatcher serves the other streams: with ONE launch of several rounds it
+// keeps refilling every SIMD from that launch, and the small kernels of other handles (refinement rounds,
+// eigenvectors: a few waves each) wait until the whole batch has drained -- tens of milliseconds with several scans in
+// flight (kernel trace of bench.py).  Costs one launch per round, changes no result.
 template <bool ELL0, bool UNIFORM, int LPF>
 static hipError_t launch_hex_lpf(const LaunchArgs& a) {
-  const unsigned blocks = (unsigned)((a.n * LPF + 63) / 64);
-  det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags, a.table, a.sys_index);
-  return hipGetLastError();
+  constexpr size_t kFreqs = 64 / LPF;
+  const size_t waves = (a.n + kFreqs - 1) / kFreqs;
+  size_t per_launch = waves;
+  // only for kernels that run one wave per SIMD (Colloc8, Magnus8: a wave owns the SIMD's register file, nothing else
+  // fits beside it, and all waves of a round end together); with two or more waves per SIMD the pieces' ragged ends
+  // cost ~10 % and the other streams' kernels find room anyway
+  if (a.hex_rounds_per_launch > 0 && hex_min_waves(STORM_SCHEME) == 1 && hex_wave_slots<ELL0, UNIFORM, LPF>() <= 1024)
+    per_launch = hex_wave_slots<ELL0, UNIFORM, LPF>() * size_t(a.hex_rounds_per_launch);
+  for (size_t w0 = 0; w0 < waves; w0 += per_launch) {
+    const size_t off = w0 * kFreqs;
+    const size_t n = std::min(a.n - off, per_launch * kFreqs);
+    const unsigned blocks = (unsigned)((n + kFreqs - 1) / kFreqs);
+    det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(
+        a.sys, a.freq + off, n, a.out + off, a.flags, a.table, a.sys_index ? a.sys_index + off : nullptr);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_hex_v(const LaunchArgs& a) {
@@ -60,8 +82,8 @@ static hipError_t launch_hex_v(const LaunchArgs& a) {
 }
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_build_v(const LaunchArgs& a) {
-  const dim3 grid((unsigned)((a.sys.n_int + 255) / 256), (unsigned)a.n, 1);
-  build_steps_kernel<STORM_SCHEME, ELL0, UNIFORM><<<grid, 256, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags, a.table, a.sys_index);
+  const dim3 grid((unsigned)((a.sys.n_int + kBuildBlock - 1) / kBuildBlock), (unsigned)a.n, 1);
+  build_steps_kernel<STORM_SCHEME, ELL0, UNIFORM><<<grid, kBuildBlock, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags, a.table, a.sys_index);
   return hipGetLastError();
 }
 

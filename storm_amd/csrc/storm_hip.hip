@@ -222,6 +222,7 @@ struct storm_solver {
   size_t quad_min_n = size_t(1) << 62;           // auto: quad kernel from this batch size on (off by default)
   size_t hex_min_n = 512;                        // auto: 16/32-lanes-per-frequency kernel from this batch size on
   int hex_lanes = 0;                             // lanes per frequency of that kernel: 0 = by wave-slot packing, 16, 32
+  int hex_rounds = 1;                            // wave rounds per launch of that kernel, 0 = the whole batch in one launch
   int eigen_layout = 0;                          // eigenvector kernels: 0 = by mode count, 1 wave per mode, 2 lane per mode
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
@@ -414,7 +415,7 @@ void check_flags(storm_solver* s) {
 LaunchArgs make_args(storm_solver* s, const double* d_freq, size_t n, double* out, hipStream_t st) {
   LaunchArgs a;
   a.sys = s->sys; a.freq = d_freq; a.n = n; a.out = out; a.flags = s->d_flags.p;
-  a.ell0 = s->ell0; a.uniform = s->uniform; a.hex_lanes = s->hex_lanes; a.stream = st;
+  a.ell0 = s->ell0; a.uniform = s->uniform; a.hex_lanes = s->hex_lanes; a.hex_rounds_per_launch = s->hex_rounds; a.stream = st;
   return a;
 }
 
@@ -808,6 +809,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     } else if (k == "hex_lanes") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
       s->hex_lanes = int(value);
+    } else if (k == "hex_rounds") {
+      if (value < 0 || value > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "hex_rounds must be 0 (one launch) .. 1024");
+      s->hex_rounds = int(value);
     } else if (k == "eigen_layout") {
       if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "eigen_layout must be 0 (auto), 1 (wave per mode) or 2 (lane per mode)");
       s->eigen_layout = int(value);
@@ -1265,7 +1269,7 @@ struct storm_sweep {
   DevBuf<CouplingArgs> d_cp_table;
   PinnedBuf h_cp;
   PinnedBuf h_in, h_out, h_flags;
-  int arith = 0, hex_lanes = 0, eigen_layout = 0;
+  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0;
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
   storm_stats stats{};
   std::mutex mu;
@@ -1294,7 +1298,7 @@ LaunchArgs set_args(storm_sweep* q, int cls, size_t first, size_t n, double* out
   LaunchArgs a;
   a.sys = q->h_table[q->cls_begin[cls]];
   a.freq = q->d_freq.p + first; a.n = n; a.out = out; a.flags = q->d_flags.p;
-  a.ell0 = set_class_ell0(cls); a.uniform = set_class_uniform(cls); a.hex_lanes = q->hex_lanes; a.stream = q->stream;
+  a.ell0 = set_class_ell0(cls); a.uniform = set_class_uniform(cls); a.hex_lanes = q->hex_lanes; a.hex_rounds_per_launch = q->hex_rounds; a.stream = q->stream;
   a.table = q->d_table.p; a.sys_index = q->d_sys.p + first;
   return a;
 }
@@ -1607,6 +1611,9 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "hex_lanes") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 16 or 32");
       q->hex_lanes = int(value);
+    } else if (k == "hex_rounds") {
+      if (value < 0 || value > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "hex_rounds must be 0 (one launch) .. 1024");
+      q->hex_rounds = int(value);
     } else if (k == "eigen_layout") {
       if (value < 0 || value > 2) fail(STORM_ERR_INVALID_ARGUMENT, "eigen_layout must be 0 (auto), 1 (wave per mode) or 2 (lane per mode)");
       q->eigen_layout = int(value);

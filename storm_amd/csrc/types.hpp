@@ -66,6 +66,7 @@ struct LaunchArgs {
   int* flags;          // device
   bool ell0, uniform;
   int hex_lanes;       // det_hex only: lanes per frequency, 16 or 32; 0 = pick by wave-slot packing
+  int hex_rounds_per_launch = 1;  // det_hex only: a batch goes out in pieces of this many wave rounds; 0 = one launch
   hipStream_t stream;
   // Several systems in one launch (storm_sweep): frequency i belongs to system
   // table[sys_index[i]] (device arrays).  All systems of a launch share n_int, the scheme and the (ell0, uniform)
