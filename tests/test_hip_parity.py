@@ -329,3 +329,29 @@ def test_host_scan_command(host, host_models, oracle, oracle_models):
     assert same_bits([r["root"] for r in rres], [g["root"] for g in res])
     _, rvec = o.eigenvector(np.array([r["root"] for r in rres]), threads=16)
     assert same_bits(rvec, vecs)
+
+
+@pytest.mark.parametrize("scheme", ["colloc8", "magnus8", "colloc4"])
+def test_batches_sent_in_pieces_of_wave_rounds(oracle, oracle_models, scheme):
+    # option "hex_rounds": a batch with more waves than the GPU has slots goes out as several launches of whole wave
+    # rounds (one-wave-per-SIMD schemes; for the others the option changes nothing): 3000 frequencies at 32 lanes each
+    # are 1500 waves for 1024 slots.  Same bits as one launch; a random sample is checked against the oracle.
+    model = oracle_models("zams")
+    o = oracle.Solver(model, 2, 0, scheme, model.field("r_coord"))
+    h = hip_from_oracle(o)
+    freqs = oracle.linspace(0.7, 30.0, 3001)[:-1]
+    h.set_option("path", 4)
+    results = {}
+    for lanes in (16, 32):
+        h.set_option("hex_lanes", lanes)
+        for rounds in (0, 1, 2):
+            h.set_option("hex_rounds", rounds)
+            results[(lanes, rounds)] = h.det(freqs)
+    first = results[(16, 0)]
+    for key, got in results.items():
+        assert np.array_equal(got.view(np.uint64), first.view(np.uint64)), key
+    pick = np.random.default_rng(5).choice(freqs.size, 64, replace=False)
+    ref = o.det(freqs[pick], threads=16)
+    assert np.array_equal(first[pick].view(np.uint64), ref.view(np.uint64))
+    with pytest.raises(Exception):
+        h.set_option("hex_rounds", -1)
