@@ -10,6 +10,7 @@ scheme = sys.argv[3] if len(sys.argv) > 3 else "colloc8"
 model = host.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_tams.npz"))
 s = host.ErasedSolver(model, 3, 0, scheme, model.field("r_coord"))
 s.set_option("path", path)
+s.set_option("hex_rounds", 0)  # the whole batch in one launch, like the roofline leg of bench.py
 f = host.linspace(1.0, 25.0, 10000)
 for _ in range(reps):
     d = s.det(f)
