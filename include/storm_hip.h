@@ -81,7 +81,9 @@ int storm_det_batch(storm_solver* solver, const double* freq, size_t n, double* 
 
 /* Same with device pointers (inputs/outputs resident in HBM), asynchronous on `hip_stream`
  * (a hipStream_t, may be NULL for the solver's own stream, in which case the call returns
- * after the work completed). */
+ * after the work completed).  On a caller's stream the call waits (on the device) for the handle's asynchronous
+ * create-time upload, returns without synchronising and cannot report STORM_ERR_SINGULAR: a singular stage matrix
+ * shows as NaN in d_det_out. */
 int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
 
 /* Replaces ErasedSolver::scan_and_optimize (src/dynamic_interface.rs:116-160): discriminant on
@@ -93,6 +95,18 @@ int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n,
 int storm_scan_and_optimize(storm_solver* solver, const double* freq, size_t n, uint64_t ulp,
                             storm_bracket* out, size_t cap, size_t* n_out, int* had_invalid,
                             double* det_out, uint64_t* index_out);
+
+/* The two halves of ErasedSolver::scan_and_optimize as separate calls, for callers that redistribute the brackets
+ * between the halves (a frequency grid sharded over several GPUs: every GPU scans a slice, the brackets are dealt out
+ * evenly for refinement).
+ * storm_scan_brackets = the first half (src/dynamic_interface.rs:125-138): discriminants, FilterSignSwap
+ * (src/bracket.rs:236-250), finite filter.  out[k] has lo_x/lo_f/hi_x/hi_f set, root = NaN, evals = 0.
+ * storm_optimize_brackets = the second half (src/dynamic_interface.rs:139-151): InverseQuadratic::optimize
+ * (src/bracket.rs:148-223) on each of the n brackets, in place; only lo_* and hi_* are read.  STORM_ERR_BRACKET where
+ * the reference asserts or panics (non-finite end points, end values of equal sign, src/bracket.rs:159-166). */
+int storm_scan_brackets(storm_solver* solver, const double* freq, size_t n, storm_bracket* out, size_t cap,
+                        size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out);
+int storm_optimize_brackets(storm_solver* solver, storm_bracket* brackets, size_t n, uint64_t ulp);
 
 /* Replaces the `eigenvector` closure = determinant_with_upper + UpperResult::eigenvectors
  * (src/dynamic_interface.rs:213-219, src/solver.rs:100-131,271-433), batched over modes.

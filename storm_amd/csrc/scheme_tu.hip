@@ -7,6 +7,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 
 namespace STORM_NS {
 using namespace storm;
@@ -32,13 +33,19 @@ static hipError_t launch_quad_v(const LaunchArgs& a) {
 // instructions: calibrated on the box, scripts/kernel_bench.py --lanes): pick the cheaper packing.
 template <bool ELL0, bool UNIFORM, int LPF>
 static size_t hex_wave_slots() {
-  static const size_t slots = [] {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF>, 64, 0) != hipSuccess)
-      return size_t(1024);
-    return size_t(cus > 0 ? cus : 256) * size_t(per_cu > 0 ? per_cu : 4);
-  }();
+  // per device: the current device's CU count x resident workgroups per CU (cached; 0 = not asked yet)
+  constexpr int kMaxDev = 64;
+  static std::atomic<size_t> cache[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return size_t(1024);
+  const bool cached = dev >= 0 && dev < kMaxDev;
+  if (cached) { const size_t v = cache[dev].load(std::memory_order_relaxed); if (v) return v; }
+  int cus = 0, per_cu = 0;
+  size_t slots = 1024;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF>, 64, 0) == hipSuccess)
+    slots = size_t(cus > 0 ? cus : 256) * size_t(per_cu > 0 ? per_cu : 4);
+  if (cached) cache[dev].store(slots, std::memory_order_relaxed);
   return slots;
 }
 template <bool ELL0, bool UNIFORM, int LPF>

@@ -98,6 +98,7 @@ class MemoryCache {
     void* p = nullptr;
     hipError_t e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
     if (e != hipSuccess) {  // make room and try once more
+      (void)hipGetLastError();  // clear HIP's sticky error: the launch wrappers return hipGetLastError()
       trim();
       e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
     }
@@ -227,6 +228,11 @@ struct storm_solver {
   storm_stats stats{};
   // optional per-kernel timing with HIP events on the launch stream (option "profile")
   hipEvent_t sync_marker = nullptr;
+  // `ready`: recorded on `stream` behind the create-time upload of the planes and the flag memset; a launch on a
+  // caller's stream (storm_det_batch_device) waits for it.  `steps_done`: recorded behind the last kernel that read
+  // d_steps, on `steps_user`; another stream waits for it before it overwrites (or the host before it recycles) d_steps.
+  hipEvent_t ready = nullptr, steps_done = nullptr;
+  hipStream_t steps_user = nullptr;
   bool profile = false;
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
@@ -412,15 +418,30 @@ void check_flags(storm_solver* s) {
   }
 }
 
-LaunchArgs make_args(storm_solver* s, const double* d_freq, size_t n, double* out, hipStream_t st) {
+LaunchArgs make_args(storm_solver* s, const double* d_freq, size_t n, double* out, hipStream_t st, int* flags = nullptr) {
   LaunchArgs a;
-  a.sys = s->sys; a.freq = d_freq; a.n = n; a.out = out; a.flags = s->d_flags.p;
+  a.sys = s->sys; a.freq = d_freq; a.n = n; a.out = out; a.flags = flags ? flags : s->d_flags.p;
   a.ell0 = s->ell0; a.uniform = s->uniform; a.hex_lanes = s->hex_lanes; a.hex_rounds_per_launch = s->hex_rounds; a.stream = st;
   return a;
 }
 
+// d_steps is shared by every stream the handle is used with.  Before `st` writes it: wait (on the device) for the last
+// reader if that ran on another stream; if the block is about to be recycled the host waits for that reader as well
+// (DevBuf::reserve only synchronises the stream it is given).
+void steps_acquire(storm_solver* s, hipStream_t st) {
+  if (!s->steps_user || s->steps_user == st) return;
+  hip_check(hipStreamWaitEvent(st, s->steps_done, 0), "hipStreamWaitEvent");
+  hip_check(hipEventSynchronize(s->steps_done), "hipEventSynchronize");
+}
+void steps_release(storm_solver* s, hipStream_t st) {
+  if (st == s->stream) { s->steps_user = nullptr; return; }  // the library stream is synchronised before every return
+  if (!s->steps_done) hip_check(hipEventCreateWithFlags(&s->steps_done, hipEventDisableTiming), "hipEventCreate");
+  hip_check(hipEventRecord(s->steps_done, st), "hipEventRecord");
+  s->steps_user = st;
+}
+
 // Core: discriminants of n device-resident frequencies into a device buffer, on stream st.
-void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, hipStream_t st) {
+void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, hipStream_t st, int* flags = nullptr) {
   if (n == 0) return;
   const size_t n_int = s->sys.n_int;
   const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
@@ -428,17 +449,17 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
   const bool hex = s->path == 4 || (s->path == 0 && !fused && !quad && n >= s->hex_min_n);
   if (hex) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_HEX);
-    hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_hex launch");
+    hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st, flags)), "det_hex launch");
     t.stop();
     count_launch(s);
   } else if (quad) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_QUAD);
-    hip_check(g_launch_quad[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_quad launch");
+    hip_check(g_launch_quad[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st, flags)), "det_quad launch");
     t.stop();
     count_launch(s);
   } else if (fused) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_FUSED);
-    hip_check(g_launch_fused[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st)), "det_fused launch");
+    hip_check(g_launch_fused[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st, flags)), "det_fused launch");
     t.stop();
     count_launch(s);
   } else {
@@ -447,17 +468,19 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     if (chunk == 0) chunk = 1;
     if (chunk > n) chunk = n;
     if (chunk > 65535) chunk = 65535;  // grid.y limit
+    steps_acquire(s, st);
     s->d_steps.reserve(chunk * n_int * 16, st);
     for (size_t off = 0; off < n; off += chunk) {
       const size_t m = std::min(chunk, n - off);
       ScopedTimer tb(s, st, STORM_KERNEL_BUILD_STEPS);
-      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st)), "build_steps launch");
+      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st, flags)), "build_steps launch");
       tb.stop();
       ScopedTimer tc(s, st, STORM_KERNEL_CHAIN);
       hip_check((s->arith ? storm_fast::launch_chain : storm::launch_chain)(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
       tc.stop();
       count_launch(s, 2);
     }
+    steps_release(s, st);
   }
   s->stats.det_evals += n;
 }
@@ -566,6 +589,8 @@ size_t eigen_reserve(storm_solver* s, size_t n) {
   if (chunk > n) chunk = n;
   if (chunk > 65535) chunk = 65535;
   s->d_freq.reserve(chunk, s->stream); s->d_det.reserve(chunk, s->stream);
+  steps_acquire(s, s->stream);
+  s->steps_user = nullptr;
   s->d_steps.reserve(chunk * n_int * 16 + 16, s->stream);
   s->d_upper.reserve((chunk + 64) * ustride, s->stream);  // lane-per-mode kernels pad the mode count to 64
   s->d_vec.reserve((chunk + 64) * len, s->stream);
@@ -745,8 +770,10 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     // path, which serialises concurrent creates)
     hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, tab_elems * sizeof(double), hipMemcpyHostToDevice, s->stream),
               "planes H2D");
-    s->d_flags.reserve(1);
-    hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), s->stream), "flags memset");
+    s->d_flags.reserve(2);  // [0]: calls on the library stream (read back and reset by check_flags), [1]: caller streams
+    hip_check(hipMemsetAsync(s->d_flags.p, 0, 2 * sizeof(int), s->stream), "flags memset");
+    hip_check(hipEventCreateWithFlags(&s->ready, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventRecord(s->ready, s->stream), "hipEventRecord");
     // no wait: every later kernel of this handle runs on the same stream, behind the upload; the pinned staging
     // buffer belongs to the handle and is next written only after a synchronisation of that stream
     s->sys.tab = s->tab.p;
@@ -778,6 +805,8 @@ void storm_solver_destroy(storm_solver* s) {
   for (auto& t : s->pending) { if (t.start) (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
   if (s->sync_marker) (void)hipEventDestroy(s->sync_marker);
+  if (s->steps_done) { (void)hipEventSynchronize(s->steps_done); (void)hipEventDestroy(s->steps_done); }
+  if (s->ready) (void)hipEventDestroy(s->ready);
   s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
   s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release(); s->h_flags.release();
   (void)hipSetDevice(prev);
@@ -860,52 +889,98 @@ int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, doub
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard g(s->device);
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
-    det_device(s, d_freq, n, d_out, st);
-    if (!hip_stream) check_flags(s);
+    if (st != s->stream) {
+      // the planes were uploaded asynchronously on the library stream by storm_solver_create
+      hip_check(hipStreamWaitEvent(st, s->ready, 0), "hipStreamWaitEvent");
+      // a singular stage shows as NaN in d_out; its flag goes to a word of its own that no later call reports
+      det_device(s, d_freq, n, d_out, st, s->d_flags.p + 1);
+    } else {
+      det_device(s, d_freq, n, d_out, st);
+      check_flags(s);
+    }
   });
+}
+
+// FilterSignSwap + finite filter (src/bracket.rs:236-250, src/dynamic_interface.rs:128-138) over the n scan values.
+static void filter_sign_swaps(const double* freq, const double* dets, size_t n, std::vector<BracketState>& br,
+                              std::vector<uint64_t>& idx, bool& invalid) {
+  invalid = false;
+  for (size_t i = 0; i + 1 < n; ++i) {
+    const double a = dets[i], b = dets[i + 1];
+    if (sign_of(a) != sign_of(b)) {
+      if (std::isfinite(a) && std::isfinite(b)) {
+        BracketState st;
+        st.lower = Pt{freq[i], a};
+        st.upper = Pt{freq[i + 1], b};
+        br.push_back(st);
+        idx.push_back(i);
+      } else {
+        invalid = true;
+      }
+    }
+  }
+}
+
+static void scan_impl(storm_solver* s, const double* freq, size_t n, bool refine, uint64_t ulp, storm_bracket* out,
+                      size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (!s || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(s->mu);
+  DeviceGuard g(s->device);
+  std::vector<double> local;
+  double* dets = det_out;
+  if (!dets) { local.resize(n); dets = local.data(); }
+  det_host(s, freq, n, dets);
+  std::vector<BracketState> br;
+  std::vector<uint64_t> idx;
+  bool invalid = false;
+  filter_sign_swaps(freq, dets, n, br, idx, invalid);
+  if (had_invalid) *had_invalid = invalid ? 1 : 0;
+  *n_out = br.size();
+  if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+  for (const BracketState& b : br)
+    if (!std::isfinite(b.lower.x) || !std::isfinite(b.upper.x))
+      fail(STORM_ERR_BRACKET, "non-finite scan frequency");
+  if (refine) refine_all(s, br, ulp);
+  for (size_t k = 0; k < br.size(); ++k) {
+    out[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f,
+                           refine ? br[k].root : std::numeric_limits<double>::quiet_NaN(), br[k].evals};
+    if (index_out) index_out[k] = idx[k];
+  }
 }
 
 int storm_scan_and_optimize(storm_solver* s, const double* freq, size_t n, uint64_t ulp, storm_bracket* out,
                             size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
   if (n_out) *n_out = 0;
   if (had_invalid) *had_invalid = 0;
+  return guarded([&] { scan_impl(s, freq, n, true, ulp, out, cap, n_out, had_invalid, det_out, index_out); });
+}
+
+int storm_scan_brackets(storm_solver* s, const double* freq, size_t n, storm_bracket* out, size_t cap, size_t* n_out,
+                        int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (n_out) *n_out = 0;
+  if (had_invalid) *had_invalid = 0;
+  return guarded([&] { scan_impl(s, freq, n, false, 1, out, cap, n_out, had_invalid, det_out, index_out); });
+}
+
+int storm_optimize_brackets(storm_solver* s, storm_bracket* brackets, size_t n, uint64_t ulp) {
   return guarded([&] {
-    if (!s || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (!s || (n && !brackets)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard g(s->device);
-    std::vector<double> local;
-    double* dets = det_out;
-    if (!dets) { local.resize(n); dets = local.data(); }
-    det_host(s, freq, n, dets);
-    // FilterSignSwap + finite filter (src/bracket.rs:236-250, src/dynamic_interface.rs:128-138)
-    std::vector<BracketState> br;
-    std::vector<uint64_t> idx;
-    bool invalid = false;
-    for (size_t i = 0; i + 1 < n; ++i) {
-      const double a = dets[i], b = dets[i + 1];
-      if (sign_of(a) != sign_of(b)) {
-        if (std::isfinite(a) && std::isfinite(b)) {
-          BracketState st;
-          st.lower = Pt{freq[i], a};
-          st.upper = Pt{freq[i + 1], b};
-          br.push_back(st);
-          idx.push_back(i);
-        } else {
-          invalid = true;
-        }
-      }
+    std::vector<BracketState> br(n);
+    for (size_t k = 0; k < n; ++k) {
+      const storm_bracket& b = brackets[k];
+      // InverseQuadratic::optimize asserts finite end values of opposite sign (src/bracket.rs:159-166)
+      if (!std::isfinite(b.lo_x) || !std::isfinite(b.hi_x) || !std::isfinite(b.lo_f) || !std::isfinite(b.hi_f))
+        fail(STORM_ERR_BRACKET, "bracket end points must be finite");
+      if (sign_of(b.lo_f) == sign_of(b.hi_f)) fail(STORM_ERR_BRACKET, "bracket end values must differ in sign");
+      br[k].lower = Pt{b.lo_x, b.lo_f};
+      br[k].upper = Pt{b.hi_x, b.hi_f};
     }
-    if (had_invalid) *had_invalid = invalid ? 1 : 0;
-    *n_out = br.size();
-    if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
-    for (const BracketState& b : br)
-      if (!std::isfinite(b.lower.x) || !std::isfinite(b.upper.x))
-        fail(STORM_ERR_BRACKET, "non-finite scan frequency");
     refine_all(s, br, ulp);
-    for (size_t k = 0; k < br.size(); ++k) {
-      out[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f, br[k].root, br[k].evals};
-      if (index_out) index_out[k] = idx[k];
-    }
+    for (size_t k = 0; k < n; ++k)
+      brackets[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f, br[k].root, br[k].evals};
   });
 }
 

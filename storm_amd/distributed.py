@@ -73,6 +73,54 @@ def sharded_scan_and_optimize(solver, freqs, ulp, device="cpu"):
     return unpack(rec), any_inv, res
 
 
+def deal(n_brackets, world, rank):
+    """Global bracket indices rank `rank` refines: dealt out cyclically by global bracket index, so a slice
+    of the grid that is dense in modes (g modes) does not serialise on the rank that scanned it."""
+    return list(range(rank, n_brackets, world))
+
+
+def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None):
+    """scan_and_optimize of ONE frequency grid split over the ranks of the default process group (strong scaling).
+
+    Every rank evaluates a contiguous slice (+1 halo point) and finds its sign swaps (`solver.scan_brackets`); the
+    unrefined brackets are gathered (all_gather of counts, all_gather of padded records), dealt out cyclically, refined
+    where they were dealt (`solver.optimize_brackets`), and the refined records are gathered again (one all_gather: the
+    deal fixes every rank's count).  `after_refine(my_brackets)` runs between refinement and the last gather (the
+    eigenvectors of this rank's modes).  Returns (all brackets in ascending order, any_invalid, this rank's brackets).
+
+    `solver` needs .scan_brackets(freqs) -> (brackets with 'index', dets, invalid) and
+    .optimize_brackets(brackets, ulp) -> brackets."""
+    freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        res, _, inv = solver.scan_brackets(freqs)
+        res = solver.optimize_brackets(res, ulp)
+        if after_refine is not None:
+            after_refine(res)
+        return res, inv, res
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, mine = local_slice(freqs, world, rank)
+    found, _, inv = solver.scan_brackets(mine) if len(mine) > 1 else ([], None, False)
+    rec, any_inv = gather_brackets(pack(found, lo), inv, device)
+    share = deal(rec.shape[0], world, rank)
+    my = solver.optimize_brackets(unpack(rec[share]), ulp) if share else []
+    if after_refine is not None:
+        after_refine(my)
+    # second exchange: every rank's count follows from the deal, so one all_gather of padded records is enough
+    cap = max(1, -(-rec.shape[0] // world))
+    buf = torch.zeros((cap, RECORD), dtype=torch.float64)
+    if my:
+        buf[:len(my)] = torch.from_numpy(pack(my, 0))
+    buf = buf.to(device)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    out = np.zeros((rec.shape[0], RECORD))
+    for r in range(world):
+        idx = deal(rec.shape[0], world, r)
+        if idx:
+            out[idx] = bufs[r][:len(idx)].cpu().numpy()
+    return unpack(out), any_inv, my
+
+
 # ---- rotation sweeps (storm_sweep): systems are independent, so they are dealt out whole ----
 def shard_systems(n_sys, world, rank):
     """Indices of the systems rank `rank` runs: contiguous blocks (systems of one rotation rate sit next to each other

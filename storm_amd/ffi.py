@@ -65,7 +65,7 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
            "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
            "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices",
-           "storm_sweep_coupling_matrices_batch"]
+           "storm_sweep_coupling_matrices_batch", "storm_scan_brackets", "storm_optimize_brackets"]
 
 _lib = None
 
@@ -90,6 +90,9 @@ def load_library():
     L.storm_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_uint64, C.POINTER(Bracket), C.c_size_t,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
     L.storm_eigenvector_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp]
+    L.storm_scan_brackets.argtypes = [C.c_void_p, _dp, C.c_size_t, C.POINTER(Bracket), C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
+    L.storm_optimize_brackets.argtypes = [C.c_void_p, C.POINTER(Bracket), C.c_size_t, C.c_uint64]
     L.storm_precision_relative_to_ulp.restype = C.c_uint64
     L.storm_precision_relative_to_ulp.argtypes = [C.c_double]
     L.storm_solver_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
@@ -197,10 +200,20 @@ class HipSolver:
         self._h = h
         self.n_int, self.p, self.scheme = n_int, p, scheme
 
+    @classmethod
+    def borrow(cls, raw_handle, owner=None):
+        """A view of a storm_solver* that someone else owns (e.g. host.ErasedSolver.raw_handle()); `owner` is kept alive."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(raw_handle)
+        self._borrowed, self._owner = True, owner
+        self.n_int = int(load_library().storm_solver_n_int(self._h))
+        self.p = self.scheme = None
+        return self
+
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
             load_library().storm_solver_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -242,6 +255,35 @@ class HipSolver:
         res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
                     index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
         return res, dets, bool(inv.value)
+
+    def scan_brackets(self, freqs, cap=None, want_dets=True):
+        """storm_scan_brackets: the unrefined sign-swap brackets (root = NaN, evals = 0) -> (brackets, dets, invalid)."""
+        f = _f64(freqs)
+        cap = max(1, f.size) if cap is None else cap
+        out = (Bracket * max(cap, 1))()
+        idx = (C.c_uint64 * max(cap, 1))()
+        dets = np.empty(f.size) if want_dets else None
+        n_out, inv = C.c_size_t(0), C.c_int(0)
+        _check(load_library().storm_scan_brackets(self._h, _p(f), f.size, out, cap, C.byref(n_out), C.byref(inv),
+                                                  _p(dets) if want_dets else None, idx))
+        res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
+                    index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
+        return res, dets, bool(inv.value)
+
+    def optimize_brackets(self, brackets, ulp):
+        """storm_optimize_brackets on a list of dicts with lo_x, lo_f, hi_x, hi_f (other keys are kept)."""
+        n = len(brackets)
+        arr = (Bracket * max(n, 1))()
+        for k, b in enumerate(brackets):
+            arr[k] = Bracket(b["lo_x"], b["lo_f"], b["hi_x"], b["hi_f"], float("nan"), 0)
+        _check(load_library().storm_optimize_brackets(self._h, arr, n, ulp))
+        out = []
+        for k, b in enumerate(brackets):
+            d = dict(b)
+            d.update(lo_x=arr[k].lo_x, lo_f=arr[k].lo_f, hi_x=arr[k].hi_x, hi_f=arr[k].hi_f, root=arr[k].root,
+                     evals=int(arr[k].evals))
+            out.append(d)
+        return out
 
     def eigenvector(self, freqs):
         f = _f64(np.atleast_1d(freqs))

@@ -47,6 +47,71 @@ def test_sharded_scan_matches_single_process(tmp_path, oracle, oracle_models, wo
     assert total_local == len(ref)  # every bracket found by exactly one rank
 
 
+class _OracleHalves:
+    """Test-only stand-in for HipSolver.scan_brackets / optimize_brackets: the oracle (what is under test is the slicing,
+    the two gathers and the cyclic deal of the brackets)."""
+
+    def __init__(self, solver):
+        self.s = solver
+
+    def scan_brackets(self, freqs):
+        d = self.s.det(freqs)
+        sgn, fin = np.signbit(d), np.isfinite(d)
+        swap = (sgn[:-1] != sgn[1:]) | np.isnan(d[:-1]) | np.isnan(d[1:])
+        ok = fin[:-1] & fin[1:]
+        res = [dict(lo_x=freqs[i], lo_f=d[i], hi_x=freqs[i + 1], hi_f=d[i + 1], root=float("nan"), evals=0, index=int(i))
+               for i in np.nonzero(swap & ok)[0]]
+        return res, d, bool(np.any(swap & ~ok))
+
+    def optimize_brackets(self, brackets, ulp):
+        out = []
+        for b in brackets:
+            r = self.s.optimize(b["lo_x"], b["lo_f"], b["hi_x"], b["hi_f"], ulp)
+            r["index"] = b["index"]
+            out.append(r)
+        return out
+
+
+def _strong_worker(rank, world, port, n_freq, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import storm_ref
+    from storm_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = storm_ref.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_zams.npz"))
+        solver = _OracleHalves(storm_ref.Solver(model, 1, 0, "colloc2", model.field("r_coord")))
+        freqs = storm_ref.linspace(1.0, 25.0, n_freq)
+        seen = []
+        res, inv, mine = D.strong_scan_and_optimize(solver, freqs, 1, device="cpu", after_refine=seen.extend)
+        assert [b["index"] for b in seen] == [b["index"] for b in mine]
+        np.save(os.path.join(out_dir, f"strong{rank}.npy"), D.pack(res, 0))
+        np.save(os.path.join(out_dir, f"mine{rank}.npy"), np.array([b["index"] for b in mine], dtype=np.int64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_freq", [(2, 80), (3, 41), (2, 3)])
+def test_strong_scaling_scan_deals_brackets_and_matches_single_process(tmp_path, oracle, oracle_models, world, n_freq):
+    from storm_amd import distributed as D
+    port = 33500 + (os.getpid() % 2000) + world + n_freq
+    mp.spawn(_strong_worker, args=(world, port, n_freq, str(tmp_path)), nprocs=world, join=True)
+    model = oracle_models("zams")
+    solver = oracle.Solver(model, 1, 0, "colloc2", model.field("r_coord"))
+    ref, _, _ = solver.scan_and_optimize(oracle.linspace(1.0, 25.0, n_freq), 1, threads=8)
+    ref_rec = D.pack(ref, 0)
+    dealt = []
+    for r in range(world):
+        got = np.load(tmp_path / f"strong{r}.npy")
+        assert np.array_equal(got.view(np.uint64), ref_rec.view(np.uint64)), f"rank {r}"
+        mine = np.load(tmp_path / f"mine{r}.npy").tolist()
+        assert mine == [ref[k]["index"] for k in D.deal(len(ref), world, r)]   # cyclic by global bracket index
+        dealt += mine
+    assert sorted(dealt) == [b["index"] for b in ref]  # every bracket refined by exactly one rank
+
+
 def test_shard_bounds_cover_every_pair_once():
     from storm_amd import distributed as D
     for n in (0, 1, 2, 7, 64, 100001):

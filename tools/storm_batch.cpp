@@ -309,6 +309,7 @@ static int run(int argc, char** argv) {
       // Resident path: the threads only deform (host, as in the reference); the integrals of every block of the group
       // then go out as ONE launch.  Host-fields path: each thread also integrates its blocks (one launch per block).
       auto work = [&] {
+        if (device >= 0) (void)hipSetDevice(device);  // per-thread in HIP (the handles guard their own device as well)
         for (size_t at; (at = next.fetch_add(1)) < tasks.size();) {
           try {
             Task& tk = tasks[at];
@@ -402,6 +403,14 @@ static int run(int argc, char** argv) {
     std::string error;
     std::mutex error_mu;
     auto worker = [&] {
+      // HIP's current device is per host thread: every thread that creates handles selects it (handles take their
+      // device from hipGetDevice at creation)
+      if (device >= 0 && hipSetDevice(device) != 0) {
+        std::lock_guard<std::mutex> lock(error_mu);
+        if (error.empty()) error = "cannot select the device in a pipeline thread";
+        failed = 1;
+        return;
+      }
       for (size_t gi; !failed.load() && (gi = next.fetch_add(1)) < n_groups;) {
         try {
           if (process_group(gi) != 0) failed = 1;
