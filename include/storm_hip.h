@@ -276,7 +276,8 @@ int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
 /* Per-kernel device time, measured with HIP events recorded on the launch stream around every
  * launch while option "profile" is 1.  ms_out / launches_out have STORM_KERNEL_KINDS entries. */
 enum { STORM_KERNEL_DET_FUSED = 0, STORM_KERNEL_BUILD_STEPS = 1, STORM_KERNEL_CHAIN = 2, STORM_KERNEL_EIGEN = 3,
-       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_DET_HEX = 5, STORM_KERNEL_POSTPROCESS = 6, STORM_KERNEL_KINDS = 7 };
+       STORM_KERNEL_DET_QUAD = 4, STORM_KERNEL_DET_HEX = 5, STORM_KERNEL_POSTPROCESS = 6, STORM_KERNEL_SEGMENTS = 7,
+       STORM_KERNEL_KINDS = 8 };
 int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* launches_out, int reset);
 
 /* Options.  Every "path" is bit-identical; only "arithmetic" = 1 changes results (to rounding).
@@ -297,6 +298,16 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *   "hex_min_n" / "quad_min_n": batch sizes from which "path" 0 picks those kernels (below: build + ordered product)
  *   "steps_bytes_max": cap of the step-matrix staging buffer in bytes (default 4 GiB)
  *   "fused_min_n": batch size from which "path" 0 picks the fused kernel
+ *   "segments": FMA build only ("arithmetic" = 1; ignored in the parity build, whose association is the reference's):
+ *               batches too small to fill the GPU (bracket-refinement rounds, single det calls, the eigenvectors of a
+ *               scan's modes) cut the interval axis into segments evaluated in parallel.  Discriminants: the ordered
+ *               product of the segments' transfer matrices (same algorithm, products associated by segment).
+ *               Eigenvectors: the reference's pivoted elimination on the segment-boundary unknowns (multiple shooting),
+ *               then y_{i+1} = L_i y_i inside every segment; a mode whose segment transfer matrices exceed 2^24 in
+ *               magnitude (strongly evanescent zone: forward propagation would amplify rounding) is sent through the
+ *               sequential elimination instead.  0 (default) automatic segment length, -1 off, > 0 forced length.
+ *               Tolerances as for "arithmetic" = 1; in this mode det_out of the eigenvector calls is the discriminant of
+ *               the segment-boundary system (agrees with the reference's in magnitude to rounding, not in sign).
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 

@@ -267,6 +267,150 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Segment-parallel kernels (FMA build only; the host never picks them in the parity build).
+//
+// One det(omega) is a chain of n_int dependent 4x4 products (reference src/solver.rs:486-492); a batch of a few
+// frequencies (a bracket-refinement round, the eigenvectors of a scan's modes) leaves the GPU idle while a handful of
+// 16-lane groups walk that chain (56 ns per interval: 0.56 ms for 10^4 intervals whatever the batch).  Here the interval
+// axis is cut into n_seg contiguous segments of seg_len intervals and every (frequency, segment) pair gets its own
+// 16-lane group, built like det_hex's: phase A = 16 step matrices per round in registers -> LDS, phase B = ordered
+// product over the round.  seg_product writes the segment's transfer matrix T_s = L_{hi-1} ... L_{lo} (row-major, the
+// layout of `steps`), so the ordered-product kernel (chain, common_kernels.hip) finishes the discriminant on n_seg
+// "intervals" instead of n_int, and the eigenvector elimination runs on the n_seg-interval system whose unknowns are the
+// solution at the segment boundaries (multiple shooting); seg_fill then carries the boundary values through each segment,
+// y_{i+1} = L_i y_i, all segments at once.  Associating the product by segments changes rounding (not the algorithm),
+// which is why this is not offered in the parity build.  n_seg is a multiple of 4 so that the four groups of a wave share
+// their frequency (and, in a sweep, their system); segments past the end of the grid are empty (T_s = I).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SegSetup {
+  size_t fi;       // frequency (mode) index, wave-uniform
+  int seg;         // segment of this 16-lane group
+  size_t lo, hi;   // its intervals [lo, hi)
+};
+SDEV SegSetup seg_setup(size_t n_int, int n_seg, int seg_len) {
+  SegSetup u;
+  const size_t t0 = (size_t)blockIdx.x * 4;
+  u.fi = t0 / (size_t)n_seg;
+  u.seg = (int)(t0 - u.fi * (size_t)n_seg) + (int)(threadIdx.x >> 4);
+  u.lo = (size_t)u.seg * (size_t)seg_len;
+  u.lo = u.lo < n_int ? u.lo : n_int;
+  u.hi = u.lo + (size_t)seg_len < n_int ? u.lo + (size_t)seg_len : n_int;
+  return u;
+}
+
+// One round of a segment group: builds the step matrices of intervals i0 .. i0+15 (clamped to the grid: the surplus
+// ones are copies that phase B never applies), parks them in LDS and returns this lane's row of each.
+template <int SCHEME, bool ELL0, bool UNIFORM>
+SDEV void seg_round_build(const SystemDev& s, size_t i0, int sub, double f, const FreqTerms& ut, bool& ok,
+                          double* __restrict__ mine, const double* __restrict__ rows, double2 (&lo)[16], double2 (&hi)[16]) {
+  size_t i = i0 + sub;
+  i = i < s.n_int ? i : s.n_int - 1;
+  const M4 l = interval_step<SCHEME, ELL0, UNIFORM>(s, i, f, ut, ok);
+  __syncthreads();  // previous round's rows have been consumed
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {  // row-major: row rr = {L(rr,0..3)}
+    *reinterpret_cast<double2*>(mine + rr * 4) = make_double2(l.v[0 * 4 + rr], l.v[1 * 4 + rr]);
+    *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    lo[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride);
+    hi[k] = *reinterpret_cast<const double2*>(rows + k * kHexLaneStride + 2);
+  }
+}
+
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64) void seg_product_kernel(SystemDev s0, const double* __restrict__ freq, int n_seg, int seg_len,
+                                                         double* __restrict__ partial, unsigned long long* __restrict__ growth,
+                                                         int* __restrict__ flags, const SystemDev* __restrict__ table,
+                                                         const int* __restrict__ sys_index) {
+  constexpr int kGroup = hex_group_stride(16);
+  __shared__ __attribute__((aligned(16))) double lds[4 * kGroup];
+  const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15, r = sub & 3, c = sub >> 2;
+  const SystemDev s = pick_system(s0, table, sys_index, (size_t)blockIdx.x * 4 / (size_t)n_seg);
+  const SegSetup u = seg_setup(s.n_int, n_seg, seg_len);
+  const double f = freq[u.fi];
+  const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
+  bool ok = true;
+  double acc = (r == c) ? 1.0 : 0.0;
+  double* __restrict__ mine = lds + g * kGroup + sub * kHexLaneStride;
+  const double* __restrict__ rows = lds + g * kGroup + r * 4;
+  for (int rd = 0; rd < seg_len / 16; ++rd) {
+    const size_t i0 = u.lo + (size_t)rd * 16;
+    double2 lo[16], hi[16];
+    seg_round_build<SCHEME, ELL0, UNIFORM>(s, i0, sub, f, ut, ok, mine, rows, lo, hi);
+    if (i0 + 16 <= u.hi) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = hex_chain_step(acc, lo[k], hi[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (i0 + k < u.hi) acc = hex_chain_step(acc, lo[k], hi[k]);
+    }
+  }
+  const unsigned long long bad = __ballot(!ok);
+  const bool group_ok = ((bad >> (g * 16)) & 0xffffULL) == 0;
+  const size_t t = (size_t)blockIdx.x * 4 + g;
+  partial[t * 16 + r * 4 + c] = group_ok ? acc : __longlong_as_double(0x7ff8000000000000LL);
+  if (!group_ok && sub == 0) atomicOr(flags, 1);
+  if (growth != nullptr) {  // max |T_s| over the segments of a mode (NaN counts as huge): the eigenvector path's guard
+    unsigned long long m = (unsigned long long)__double_as_longlong(__builtin_fabs(acc));
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const unsigned long long o = __shfl_xor(m, d, 64);
+      m = o > m ? o : m;
+    }
+    if (sub == 0) atomicMax(growth + u.fi, m);
+  }
+}
+
+// y at the segment boundaries -> y at every grid point.  nodes: [mode][(n_seg + 1) * 4], vec: [mode][(n_int + 1) * 4].
+// Point lo of a segment is its boundary value; points lo+1 .. hi-1 are propagated; the last grid point comes from the
+// last boundary (whose fourth component the elimination fixed to 1, like the reference's back-substitution).
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64) void seg_fill_kernel(SystemDev s0, const double* __restrict__ freq, int n_seg, int seg_len,
+                                                      const double* __restrict__ nodes, double* __restrict__ vec,
+                                                      const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
+  constexpr int kGroup = hex_group_stride(16);
+  __shared__ __attribute__((aligned(16))) double lds[4 * kGroup];
+  const int tid = threadIdx.x, g = tid >> 4, sub = tid & 15, r = sub & 3, q = sub >> 2;
+  const SystemDev s = pick_system(s0, table, sys_index, (size_t)blockIdx.x * 4 / (size_t)n_seg);
+  const SegSetup u = seg_setup(s.n_int, n_seg, seg_len);
+  const double f = freq[u.fi];
+  const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
+  bool ok = true;
+  const size_t len = (s.n_int + 1) * 4;
+  double* __restrict__ e = vec + u.fi * len;
+  const double* __restrict__ nd = nodes + u.fi * (size_t)(n_seg + 1) * 4;
+  double y = nd[(size_t)u.seg * 4 + r];  // every quad of the group carries the same vector
+  if (q == 0 && u.lo < u.hi) e[u.lo * 4 + r] = y;
+  if (q == 0 && u.seg == n_seg - 1) e[s.n_int * 4 + r] = nd[(size_t)n_seg * 4 + r];
+  double* __restrict__ mine = lds + g * kGroup + sub * kHexLaneStride;
+  const double* __restrict__ rows = lds + g * kGroup + r * 4;
+  for (int rd = 0; rd < seg_len / 16; ++rd) {
+    const size_t i0 = u.lo + (size_t)rd * 16;
+    // (rounds past the segment's end compute values that are never stored: the trip count stays wave-uniform, so the
+    // barriers inside seg_round_build are reached by all four groups together)
+    double2 lo[16], hi[16];
+    seg_round_build<SCHEME, ELL0, UNIFORM>(s, i0, sub, f, ut, ok, mine, rows, lo, hi);
+    // step k gives y at point i0 + k + 1; lane (q, r) keeps the steps k = 4j + q, so that for fixed j the 16 lanes of the
+    // group hold 16 consecutive doubles of the eigenvector (one 128-B store)
+    double out[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      y = hex_chain_step(y, lo[k], hi[k]);
+      if ((k & 3) == q) out[k >> 2] = y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t point = i0 + 1 + 4 * j + q;
+      if (point < u.hi) e[point * 4 + r] = out[j];
+    }
+  }
+}
+
 // One wave per workgroup: a workgroup of four waves needs room on all four SIMDs of a CU at once, which it does not
 // find for tens of milliseconds while another handle's det_hex<colloc8> waves (one per SIMD, the whole register file)
 // are in flight (kernel trace of bench.py: a 0.5 ms refinement launch took 35 ms).

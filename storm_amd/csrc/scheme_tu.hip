@@ -94,6 +94,37 @@ static hipError_t launch_build_v(const LaunchArgs& a) {
   return hipGetLastError();
 }
 
+template <bool ELL0, bool UNIFORM>
+static hipError_t launch_seg_product_v(const LaunchArgs& a) {
+  const unsigned blocks = (unsigned)(a.n * (size_t)a.n_seg / 4);
+  seg_product_kernel<STORM_SCHEME, ELL0, UNIFORM><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n_seg, a.seg_len, a.out, a.growth,
+                                                                             a.flags, a.table, a.sys_index);
+  return hipGetLastError();
+}
+template <bool ELL0, bool UNIFORM>
+static hipError_t launch_seg_fill_v(const LaunchArgs& a) {
+  const unsigned blocks = (unsigned)(a.n * (size_t)a.n_seg / 4);
+  seg_fill_kernel<STORM_SCHEME, ELL0, UNIFORM><<<blocks, 64, 0, a.stream>>>(a.sys, a.freq, a.n_seg, a.seg_len, a.nodes, a.vec,
+                                                                          a.table, a.sys_index);
+  return hipGetLastError();
+}
+static bool seg_args_ok(const LaunchArgs& a) {
+  return a.sys.n_int > 0 && a.n_seg > 0 && a.n_seg % 4 == 0 && a.seg_len > 0 && a.seg_len % 16 == 0 &&
+         (size_t)a.n_seg * (size_t)a.seg_len >= a.sys.n_int && a.n * (size_t)a.n_seg / 4 < (size_t(1) << 31);
+}
+hipError_t STORM_CAT(launch_seg_product_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
+  if (a.n == 0) return hipSuccess;
+  if (!seg_args_ok(a)) return hipErrorInvalidValue;
+  if (a.ell0) return launch_seg_product_v<true, true>(a);
+  return a.uniform ? launch_seg_product_v<false, true>(a) : launch_seg_product_v<false, false>(a);
+}
+hipError_t STORM_CAT(launch_seg_fill_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
+  if (a.n == 0) return hipSuccess;
+  if (!seg_args_ok(a) || !a.nodes || !a.vec) return hipErrorInvalidValue;
+  if (a.ell0) return launch_seg_fill_v<true, true>(a);
+  return a.uniform ? launch_seg_fill_v<false, true>(a) : launch_seg_fill_v<false, false>(a);
+}
+
 hipError_t STORM_CAT(launch_fused_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   if (a.n == 0 ) return hipSuccess;
   if (a.ell0) return launch_fused_v<true, true>(a);

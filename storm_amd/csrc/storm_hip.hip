@@ -28,6 +28,8 @@
   hipError_t launch_quad_scheme_##n(const storm::LaunchArgs&);    \
   hipError_t launch_hex_scheme_##n(const storm::LaunchArgs&);     \
   hipError_t launch_build_scheme_##n(const storm::LaunchArgs&);   \
+  hipError_t launch_seg_product_scheme_##n(const storm::LaunchArgs&); \
+  hipError_t launch_seg_fill_scheme_##n(const storm::LaunchArgs&);    \
   }
 #define STORM_DECL_ALL(ns)                                                                          \
   STORM_DECL_SCHEME(ns, 0) STORM_DECL_SCHEME(ns, 1) STORM_DECL_SCHEME(ns, 2) STORM_DECL_SCHEME(ns, 3) \
@@ -49,6 +51,8 @@ static const launch_fn g_launch_fused[2][kNumSchemes] = STORM_TABLE(fused);
 static const launch_fn g_launch_quad[2][kNumSchemes] = STORM_TABLE(quad);
 static const launch_fn g_launch_hex[2][kNumSchemes] = STORM_TABLE(hex);
 static const launch_fn g_launch_build[2][kNumSchemes] = STORM_TABLE(build);
+static const launch_fn g_launch_seg_product[2][kNumSchemes] = STORM_TABLE(seg_product);
+static const launch_fn g_launch_seg_fill[2][kNumSchemes] = STORM_TABLE(seg_fill);
 
 static thread_local std::string g_error;
 
@@ -214,7 +218,14 @@ struct storm_solver {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_det, d_steps, d_upper, d_vec;
   DevBuf<int> d_swaps, d_flags;
-  PinnedBuf h_vec, h_flags;
+  // segment-parallel path (FMA build): segment transfer matrices, boundary values of the eigenvectors, max |T_s| per mode,
+  // and the staging of modes that are sent through the sequential elimination after all
+  DevBuf<double> d_partials, d_nodes, d_vec_fb, d_det_fb, d_freq_fb;
+  DevBuf<unsigned long long> d_growth;
+  PinnedBuf h_vec, h_flags, h_growth;
+  int segments = 0;                              // 0 auto (FMA build only), -1 off, > 0 forced segment length
+  const double* h_freq_last = nullptr;           // the caller's frequencies of the eigenvector chunk in flight
+  size_t classic_chunk = 1;                      // modes per pass of the sequential kernels (set by eigen_reserve)
   int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
   int path = 0;                                  // 0 auto, 1 fused, 2 split, 3 quad, 4 hex
   size_t steps_bytes_max = size_t(4) << 30;
@@ -237,8 +248,8 @@ struct storm_solver {
   struct Timed { int kind; hipEvent_t start, stop; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> event_pool;
-  double kernel_ms[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0, 0};
-  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {0, 0, 0, 0, 0, 0, 0};
+  double kernel_ms[STORM_KERNEL_KINDS] = {};
+  uint64_t kernel_launches[STORM_KERNEL_KINDS] = {};
   std::mutex mu;
 };
 
@@ -440,6 +451,40 @@ void steps_release(storm_solver* s, hipStream_t st) {
   s->steps_user = st;
 }
 
+// Segment-parallel evaluation (scheme_kernels.hpp, "Segment-parallel kernels"): how the interval axis is cut for a batch
+// of n frequencies.  n_seg == 0: not applicable.
+struct SegPlan { int n_seg = 0, seg_len = 0; };
+SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len) {
+  SegPlan p;
+  const size_t n_int = s->sys.n_int;
+  if (s->arith != 1 || s->segments < 0 || n == 0 || n_int < 64) return p;  // the parity build keeps the reference's association
+  size_t len;
+  if (s->segments > 0) {
+    len = (size_t(s->segments) + 15) / 16 * 16;
+  } else {
+    const size_t target_groups = 4096;  // 16-lane groups in flight: one wave per SIMD
+    const size_t want = std::max<size_t>(1, target_groups / n);
+    len = ((n_int + want - 1) / want + 15) / 16 * 16;
+    len = std::min(std::max<size_t>(len, 32), max_len);
+  }
+  size_t n_seg = ((n_int + len - 1) / len + 3) / 4 * 4;
+  if (n * n_seg / 4 >= (size_t(1) << 31) || n_seg > (size_t(1) << 24)) return p;
+  p.n_seg = int(n_seg); p.seg_len = int(len);
+  return p;
+}
+
+// Discriminants through segment transfer matrices: one launch over every (frequency, segment) pair, then the ordered
+// product + boundary elimination on n_seg "intervals".
+void det_segments(storm_solver* s, const SegPlan& plan, const double* d_freq, size_t n, double* d_out, hipStream_t st, int* flags) {
+  s->d_partials.reserve(n * size_t(plan.n_seg) * 16, st);
+  LaunchArgs a = make_args(s, d_freq, n, s->d_partials.p, st, flags);
+  a.n_seg = plan.n_seg; a.seg_len = plan.seg_len;
+  hip_check(g_launch_seg_product[s->arith][s->scheme](a), "seg_product launch");
+  SystemDev reduced = s->sys;
+  reduced.n_int = size_t(plan.n_seg);
+  hip_check(storm_fast::launch_chain(reduced, s->ell0, d_freq, n, s->d_partials.p, d_out, st), "chain launch");
+}
+
 // Core: discriminants of n device-resident frequencies into a device buffer, on stream st.
 void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, hipStream_t st, int* flags = nullptr) {
   if (n == 0) return;
@@ -447,7 +492,16 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
   const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
   const bool quad = s->path == 3 || (s->path == 0 && !fused && n >= s->quad_min_n);
   const bool hex = s->path == 4 || (s->path == 0 && !fused && !quad && n >= s->hex_min_n);
-  if (hex) {
+  const SegPlan plan = (s->path == 0 && !fused && !quad && !hex) ? plan_segments(s, n, n_int) : SegPlan{};
+  if (plan.n_seg) {
+    // (d_partials is used on one stream at a time: a caller's stream takes the same hand-over as d_steps)
+    steps_acquire(s, st);
+    ScopedTimer t(s, st, STORM_KERNEL_SEGMENTS);
+    det_segments(s, plan, d_freq, n, d_out, st, flags);
+    t.stop();
+    count_launch(s, 2);
+    steps_release(s, st);
+  } else if (hex) {
     ScopedTimer t(s, st, STORM_KERNEL_DET_HEX);
     hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st, flags)), "det_hex launch");
     t.stop();
@@ -595,19 +649,84 @@ size_t eigen_reserve(storm_solver* s, size_t n) {
   s->d_upper.reserve((chunk + 64) * ustride, s->stream);  // lane-per-mode kernels pad the mode count to 64
   s->d_vec.reserve((chunk + 64) * len, s->stream);
   s->d_swaps.reserve(chunk * 2, s->stream);
+  s->classic_chunk = chunk;
   return chunk;
 }
+// The sequential kernels: step matrices, pivoted elimination, back-substitution (bit-identical to the reference in the
+// parity build).  Frequencies in d_freq; eigenvectors to d_vec, discriminants to d_det.
+void eigen_classic(storm_solver* s, const double* d_freq, size_t m, double* d_vec, double* d_det) {
+  ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
+  hip_check(g_launch_build[s->arith][s->scheme](make_args(s, d_freq, m, s->d_steps.p, s->stream)), "build_steps launch");
+  tb.stop();
+  ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
+  hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0 ? 1 : 0, d_freq, m, s->d_steps.p, s->d_upper.p,
+                                                                        s->d_swaps.p, d_det, d_vec, s->stream, nullptr, nullptr, s->eigen_layout), "eigen launch");
+  te.stop();
+  count_launch(s, 3);
+}
+
+// Segment-parallel eigenvectors (FMA build; see "segments" in storm_hip.h): transfer matrices of all (mode, segment)
+// pairs, the reference's elimination + back-substitution on the n_seg-interval system of the segment boundaries, then
+// the fill of every segment.  Modes whose transfer matrices grow beyond kSegGrowthMax are redone sequentially.
+constexpr double kSegGrowthMax = 16777216.0;  // 2^24
+void eigen_segments(storm_solver* s, const SegPlan& plan, size_t m) {
+  const size_t n_seg = size_t(plan.n_seg), len = (s->sys.n_int + 1) * 4;
+  s->d_partials.reserve(m * n_seg * 16, s->stream);
+  s->d_nodes.reserve((m + 64) * (n_seg + 1) * 4, s->stream);
+  s->d_growth.reserve(m, s->stream);
+  hip_check(hipMemsetAsync(s->d_growth.p, 0, m * sizeof(unsigned long long), s->stream), "growth memset");
+  ScopedTimer ts(s, s->stream, STORM_KERNEL_SEGMENTS);
+  LaunchArgs a = make_args(s, s->d_freq.p, m, s->d_partials.p, s->stream);
+  a.n_seg = plan.n_seg; a.seg_len = plan.seg_len; a.growth = s->d_growth.p;
+  hip_check(g_launch_seg_product[s->arith][s->scheme](a), "seg_product launch");
+  ts.stop();
+  SystemDev reduced = s->sys;
+  reduced.n_int = n_seg;
+  ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
+  hip_check(storm_fast::launch_eigen(reduced, s->ell0 ? 1 : 0, s->d_freq.p, m, s->d_partials.p, s->d_upper.p, s->d_swaps.p,
+                                     s->d_det.p, s->d_nodes.p, s->stream, nullptr, nullptr, s->eigen_layout), "eigen launch");
+  te.stop();
+  ScopedTimer tf(s, s->stream, STORM_KERNEL_SEGMENTS);
+  a.nodes = s->d_nodes.p; a.vec = s->d_vec.p; a.growth = nullptr;
+  hip_check(g_launch_seg_fill[s->arith][s->scheme](a), "seg_fill launch");
+  tf.stop();
+  count_launch(s, 4);
+  // the guard: which modes have a segment whose transfer matrix is too large to propagate through?
+  s->h_growth.reserve(m);
+  hip_check(hipMemcpyAsync(s->h_growth.p, s->d_growth.p, m * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream), "growth D2H");
+  sync_stream(s->stream, s->sync_marker);
+  std::vector<size_t> redo;
+  for (size_t k = 0; k < m; ++k)
+    if (!(s->h_growth.p[k] <= kSegGrowthMax)) redo.push_back(k);  // (h_growth holds the bit patterns of |T|: read as doubles)
+  if (redo.empty()) return;
+  s->stats.segment_fallbacks += redo.size();
+  std::vector<double> f(redo.size());
+  // d_freq -> host is not needed: the caller's frequencies are still in the pinned upload area (see eigen_chunk)
+  for (size_t q = 0; q < redo.size(); ++q) f[q] = s->h_freq_last[redo[q]];
+  s->d_freq_fb.reserve(redo.size(), s->stream); s->d_vec_fb.reserve((redo.size() + 64) * len, s->stream);
+  s->d_det_fb.reserve(redo.size(), s->stream);
+  hip_check(hipMemcpyAsync(s->d_freq_fb.p, f.data(), f.size() * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
+  hip_check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");  // `f` is pageable and about to go out of scope
+  for (size_t q0 = 0; q0 < redo.size(); q0 += s->classic_chunk) {
+    const size_t k = std::min(s->classic_chunk, redo.size() - q0);
+    eigen_classic(s, s->d_freq_fb.p + q0, k, s->d_vec_fb.p, s->d_det_fb.p);
+    for (size_t q = 0; q < k; ++q) {
+      hip_check(hipMemcpyAsync(s->d_vec.p + redo[q0 + q] * len, s->d_vec_fb.p + q * len, len * sizeof(double), hipMemcpyDeviceToDevice, s->stream), "vec D2D");
+      hip_check(hipMemcpyAsync(s->d_det.p + redo[q0 + q], s->d_det_fb.p + q, sizeof(double), hipMemcpyDeviceToDevice, s->stream), "det D2D");
+    }
+  }
+}
+
 // Eigenvectors of m host frequencies into s->d_vec (and discriminants into s->d_det), left on the device.
 void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
   hip_check(hipMemcpyAsync(s->d_freq.p, freq, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
-  ScopedTimer tb(s, s->stream, STORM_KERNEL_BUILD_STEPS);
-  hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, s->stream)), "build_steps launch");
-  tb.stop();
-  ScopedTimer te(s, s->stream, STORM_KERNEL_EIGEN);
-  hip_check((s->arith ? storm_fast::launch_eigen : storm::launch_eigen)(s->sys, s->ell0 ? 1 : 0, s->d_freq.p, m, s->d_steps.p, s->d_upper.p,
-                                                                        s->d_swaps.p, s->d_det.p, s->d_vec.p, s->stream, nullptr, nullptr, s->eigen_layout), "eigen launch");
-  te.stop();
-  count_launch(s, 3);
+  const SegPlan plan = plan_segments(s, m, 256);
+  if (plan.n_seg) {
+    s->h_freq_last = freq;
+    eigen_segments(s, plan, m);
+  } else {
+    eigen_classic(s, s->d_freq.p, m, s->d_vec.p, s->d_det.p);
+  }
   s->stats.eigenvectors += m;
 }
 
@@ -809,6 +928,8 @@ void storm_solver_destroy(storm_solver* s) {
   if (s->ready) (void)hipEventDestroy(s->ready);
   s->tab.release(); s->d_freq.release(); s->d_det.release(); s->d_steps.release();
   s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release(); s->h_flags.release();
+  s->d_partials.release(); s->d_nodes.release(); s->d_vec_fb.release(); s->d_det_fb.release(); s->d_freq_fb.release();
+  s->d_growth.release(); s->h_growth.release();
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -831,7 +952,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
       s->arith = int(value);
     } else if (k == "profile") {
       s->profile = value != 0;
-
+    } else if (k == "segments") {
+      if (value < -1 || value > (1 << 20)) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be -1 (off), 0 (auto) or a segment length");
+      s->segments = int(value);
     } else if (k == "hex_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
       s->hex_min_n = size_t(value);

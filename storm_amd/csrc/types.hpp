@@ -74,6 +74,13 @@ struct LaunchArgs {
   // table == nullptr: the one system `sys`.
   const SystemDev* table = nullptr;
   const int* sys_index = nullptr;
+  // Segment-parallel kernels (seg_product, seg_fill; FMA build): n_seg segments (a multiple of 4) of seg_len intervals (a
+  // multiple of 16) per frequency; `out` = the segment transfer matrices [n][n_seg][16]; growth (may be null) =
+  // max |T_s| per frequency as raw bits; nodes / vec: seg_fill's boundary values in, eigenvectors out.
+  int n_seg = 0, seg_len = 0;
+  unsigned long long* growth = nullptr;
+  const double* nodes = nullptr;
+  double* vec = nullptr;
 };
 typedef hipError_t (*launch_fn)(const LaunchArgs&);
 

@@ -137,7 +137,7 @@ def load_library():
     return L
 
 
-KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad", "det_hex", "postprocess"]
+KERNEL_KINDS = ["det_fused", "build_steps", "chain", "eigen", "det_quad", "det_hex", "postprocess", "segments"]
 
 
 def kernel_times(handle, reset=False):

@@ -2,6 +2,9 @@ import os
 import sys
 
 import pytest
+# torch first: it bundles its own HIP runtime, and whichever copy of libamdhip64 is loaded first serves the whole process.
+# With libstorm_hip loaded first (ROCm's copy), a later torch.cuda initialisation reports "No HIP GPUs are available".
+import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
