@@ -267,9 +267,10 @@ void storm_memory_cache_stats(size_t* device_bytes, size_t* pinned_host_bytes); 
 uint64_t storm_precision_relative_to_ulp(double relative_precision);
 
 /* Work counters since creation (or the last reset): discriminant evaluations (scan + refinement
- * + single calls), of which refinement; modes whose eigenvector was computed; kernel launches. */
+ * + single calls), of which refinement; modes whose eigenvector was computed; kernel launches; modes that the
+ * segment-parallel eigenvector path ("segments") sent through the sequential elimination. */
 typedef struct {
-  uint64_t det_evals, refine_evals, refine_rounds, eigenvectors, launches;
+  uint64_t det_evals, refine_evals, refine_rounds, eigenvectors, launches, segment_fallbacks;
 } storm_stats;
 int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
 
@@ -305,7 +306,8 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *               Eigenvectors: the reference's pivoted elimination on the segment-boundary unknowns (multiple shooting),
  *               then y_{i+1} = L_i y_i inside every segment; a mode whose segment transfer matrices exceed 2^24 in
  *               magnitude (strongly evanescent zone: forward propagation would amplify rounding) is sent through the
- *               sequential elimination instead.  0 (default) automatic segment length, -1 off, > 0 forced length.
+ *               sequential elimination instead ("seg_growth_log2" moves that bound, default 24).  0 (default) automatic
+ *               segment length, -1 off, > 0 forced length.
  *               Tolerances as for "arithmetic" = 1; in this mode det_out of the eigenvector calls is the discriminant of
  *               the segment-boundary system (agrees with the reference's in magnitude to rounding, not in sign).
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */

@@ -282,6 +282,11 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 // y_{i+1} = L_i y_i, all segments at once.  Associating the product by segments changes rounding (not the algorithm),
 // which is why this is not offered in the parity build.  n_seg is a multiple of 4 so that the four groups of a wave share
 // their frequency (and, in a sweep, their system); segments past the end of the grid are empty (T_s = I).
+// The FIRST interval is a segment of its own: the reference's elimination treats its block specially (column pivoting,
+// src/solver.rs:192-230,334-339, whose second exchange leaves the already stored factors of pivot 0 in the old column
+// order), so the value it returns at grid point 0 does not satisfy y_1 = L_0 y_0 in general.  With interval 0 alone in
+// segment 0 the boundary-value system starts with the reference's own first block (point 0 comes out like the
+// reference's) and nothing is propagated from point 0.
 // ---------------------------------------------------------------------------------------------------------------------
 struct SegSetup {
   size_t fi;       // frequency (mode) index, wave-uniform
@@ -293,9 +298,15 @@ SDEV SegSetup seg_setup(size_t n_int, int n_seg, int seg_len) {
   const size_t t0 = (size_t)blockIdx.x * 4;
   u.fi = t0 / (size_t)n_seg;
   u.seg = (int)(t0 - u.fi * (size_t)n_seg) + (int)(threadIdx.x >> 4);
-  u.lo = (size_t)u.seg * (size_t)seg_len;
-  u.lo = u.lo < n_int ? u.lo : n_int;
-  u.hi = u.lo + (size_t)seg_len < n_int ? u.lo + (size_t)seg_len : n_int;
+  // segment 0 is the first interval alone, segment s >= 1 covers [1 + (s-1) seg_len, 1 + s seg_len)
+  if (u.seg == 0) {
+    u.lo = 0;
+    u.hi = n_int < 1 ? n_int : 1;
+  } else {
+    u.lo = 1 + (size_t)(u.seg - 1) * (size_t)seg_len;
+    u.lo = u.lo < n_int ? u.lo : n_int;
+    u.hi = u.lo + (size_t)seg_len < n_int ? u.lo + (size_t)seg_len : n_int;
+  }
   return u;
 }
 

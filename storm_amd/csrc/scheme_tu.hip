@@ -110,7 +110,7 @@ static hipError_t launch_seg_fill_v(const LaunchArgs& a) {
 }
 static bool seg_args_ok(const LaunchArgs& a) {
   return a.sys.n_int > 0 && a.n_seg > 0 && a.n_seg % 4 == 0 && a.seg_len > 0 && a.seg_len % 16 == 0 &&
-         (size_t)a.n_seg * (size_t)a.seg_len >= a.sys.n_int && a.n * (size_t)a.n_seg / 4 < (size_t(1) << 31);
+         (size_t)(a.n_seg - 1) * (size_t)a.seg_len + 1 >= a.sys.n_int && a.n * (size_t)a.n_seg / 4 < (size_t(1) << 31);
 }
 hipError_t STORM_CAT(launch_seg_product_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   if (a.n == 0) return hipSuccess;

@@ -224,6 +224,7 @@ struct storm_solver {
   DevBuf<unsigned long long> d_growth;
   PinnedBuf h_vec, h_flags, h_growth;
   int segments = 0;                              // 0 auto (FMA build only), -1 off, > 0 forced segment length
+  double seg_growth_max = 16777216.0;            // 2^24: larger segment transfer matrices send a mode to the sequential path
   const double* h_freq_last = nullptr;           // the caller's frequencies of the eigenvector chunk in flight
   size_t classic_chunk = 1;                      // modes per pass of the sequential kernels (set by eigen_reserve)
   int arith = 0;                                 // 0 parity (un-fused), 1 fast (FMA contraction)
@@ -467,7 +468,7 @@ SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len) {
     len = ((n_int + want - 1) / want + 15) / 16 * 16;
     len = std::min(std::max<size_t>(len, 32), max_len);
   }
-  size_t n_seg = ((n_int + len - 1) / len + 3) / 4 * 4;
+  size_t n_seg = (1 + (n_int - 1 + len - 1) / len + 3) / 4 * 4;  // the first interval is a segment of its own
   if (n * n_seg / 4 >= (size_t(1) << 31) || n_seg > (size_t(1) << 24)) return p;
   p.n_seg = int(n_seg); p.seg_len = int(len);
   return p;
@@ -668,7 +669,6 @@ void eigen_classic(storm_solver* s, const double* d_freq, size_t m, double* d_ve
 // Segment-parallel eigenvectors (FMA build; see "segments" in storm_hip.h): transfer matrices of all (mode, segment)
 // pairs, the reference's elimination + back-substitution on the n_seg-interval system of the segment boundaries, then
 // the fill of every segment.  Modes whose transfer matrices grow beyond kSegGrowthMax are redone sequentially.
-constexpr double kSegGrowthMax = 16777216.0;  // 2^24
 void eigen_segments(storm_solver* s, const SegPlan& plan, size_t m) {
   const size_t n_seg = size_t(plan.n_seg), len = (s->sys.n_int + 1) * 4;
   s->d_partials.reserve(m * n_seg * 16, s->stream);
@@ -697,7 +697,7 @@ void eigen_segments(storm_solver* s, const SegPlan& plan, size_t m) {
   sync_stream(s->stream, s->sync_marker);
   std::vector<size_t> redo;
   for (size_t k = 0; k < m; ++k)
-    if (!(s->h_growth.p[k] <= kSegGrowthMax)) redo.push_back(k);  // (h_growth holds the bit patterns of |T|: read as doubles)
+    if (!(s->h_growth.p[k] <= s->seg_growth_max)) redo.push_back(k);  // (h_growth holds the bit patterns of |T|: read as doubles)
   if (redo.empty()) return;
   s->stats.segment_fallbacks += redo.size();
   std::vector<double> f(redo.size());
@@ -955,6 +955,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
     } else if (k == "segments") {
       if (value < -1 || value > (1 << 20)) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be -1 (off), 0 (auto) or a segment length");
       s->segments = int(value);
+    } else if (k == "seg_growth_log2") {
+      if (value < 0 || value > 1000) fail(STORM_ERR_INVALID_ARGUMENT, "seg_growth_log2 must be 0..1000");
+      s->seg_growth_max = std::ldexp(1.0, int(value));
     } else if (k == "hex_min_n") {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
       s->hex_min_n = size_t(value);

@@ -33,7 +33,7 @@ class SystemDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("det_evals", C.c_uint64), ("refine_evals", C.c_uint64), ("refine_rounds", C.c_uint64),
-                ("eigenvectors", C.c_uint64), ("launches", C.c_uint64)]
+                ("eigenvectors", C.c_uint64), ("launches", C.c_uint64), ("segment_fallbacks", C.c_uint64)]
 
 
 class ModelDesc(C.Structure):
