@@ -86,6 +86,21 @@ int storm_det_batch(storm_solver* solver, const double* freq, size_t n, double* 
  * shows as NaN in d_det_out. */
 int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
 
+/* storm_det_batch_device for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels, same choice between
+ * them and same results as storm_det_batch_device with default options, but the two scratch areas they need (the
+ * singular-stage flag word, the segment transfer matrices of the "segments" path) live in a file-scope device array of
+ * STORM_NOALLOC_SCRATCH_BYTES that every GPU holds once per process, so the call reaches no hipMalloc / hipFree /
+ * hipHostMalloc and creates no event or stream.  Limits: n <= STORM_NOALLOC_MAX_N, and the segment transfer matrices of
+ * one call (128 B per (frequency, segment) pair; only batches below "hex_min_n" in the FMA build have any) must fit the
+ * scratch -- always true for the automatic segment length; STORM_ERR_CAPACITY otherwise.  A singular stage matrix shows
+ * as NaN in d_det_out (no status is read back).  hip_stream NULL: the solver's own stream, and the call returns after
+ * the work completed; otherwise asynchronous on that stream.  All allocation-free calls on one GPU share the scratch:
+ * calls that overlap on one GPU (different streams or handles) race; calls on one stream are safe. */
+#define STORM_NOALLOC_MAX_N ((size_t)1 << 24)
+#define STORM_NOALLOC_SCRATCH_BYTES (((size_t)4 << 20) + 256)
+int storm_det_batch_device_noalloc(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
+
 /* Replaces ErasedSolver::scan_and_optimize (src/dynamic_interface.rs:116-160): discriminant on
  * every grid point, sign-swap filter on adjacent points (FilterSignSwap, src/bracket.rs:236-250)
  * dropping non-finite pairs (sets *had_invalid), then InverseQuadratic::optimize

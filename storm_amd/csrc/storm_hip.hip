@@ -207,7 +207,43 @@ struct PinnedBuf {
 
 using namespace storm;
 
+// ---- scratch of the allocation-free entry point (storm_det_batch_device_noalloc) ----
+// A file-scope device array instead of a DevBuf: callers under HIP graph capture or in loops that must not reach
+// hipMalloc get the two scratch areas the discriminant kernels need -- the singular-stage flag word they atomicOr into
+// and the segment transfer matrices of the segment-parallel path -- without any allocation.  Every GPU the library runs
+// on holds its own copy until the process ends; the array's name is only a host-side handle, the device address comes
+// from hipGetSymbolAddress (once per device, at the first storm_solver_create on that device) and is what the kernels
+// receive as an argument.  All calls on one GPU share it: overlapping allocation-free calls on one GPU race.
+constexpr size_t kScratchFlagBytes = 256;                    // [0, 256): flag words
+constexpr size_t kScratchPartialBytes = size_t(4) << 20;     // then: segment transfer matrices, 128 B each
+constexpr size_t kNoallocMaxN = size_t(1) << 24;             // frequencies per call (STORM_NOALLOC_MAX_N)
+static_assert(kScratchPartialBytes == STORM_NOALLOC_SCRATCH_BYTES - 256 && kNoallocMaxN == STORM_NOALLOC_MAX_N, "storm_hip.h");
+// (no __attribute__((used)): it would keep the symbol local in the device code object, where hipGetSymbolAddress cannot
+// find it; the host-side use below is what keeps the array alive and makes hipcc export it)
+static __device__ __align__(256) unsigned char scratch[kScratchFlagBytes + kScratchPartialBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+// The current device's copy of `scratch`.
+unsigned char* scratch_of_current_device() {
+  int dev = 0;
+  hip_check(hipGetDevice(&dev), "hipGetDevice");
+  if (dev < 0 || dev >= kMaxDevices) fail(STORM_ERR_HIP, "device index out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    hip_check(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+    if (!p) fail(STORM_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    g_scratch_ptr[dev] = static_cast<unsigned char*>(p);
+  }
+  return g_scratch_ptr[dev];
+}
+}  // namespace
+
 struct storm_solver {
+  unsigned char* scratch = nullptr;  // this device's copy of the allocation-free entry point's scratch array
   int device = 0;
   int scheme = 0;
   bool ell0 = true, uniform = true;
@@ -882,6 +918,7 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
     s->tab.reserve(tab_elems, nullptr);
     s->stream = MemoryCache::get().take_stream(s->device);
+    s->scratch = scratch_of_current_device();
     // Uploads are ordered on the solver's own (non-blocking) stream: a plain hipMemcpy from pageable
     // memory is only ordered against the NULL stream, so a kernel launched on s->stream right after
     // create could otherwise read the planes before the DMA has landed.
@@ -1024,6 +1061,44 @@ int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, doub
       det_device(s, d_freq, n, d_out, st);
       check_flags(s);
     }
+  });
+}
+
+int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t n, double* d_out, void* hip_stream) {
+  return guarded([&] {
+    if (!s || (n && (!d_freq || !d_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    if (n > kNoallocMaxN) fail(STORM_ERR_CAPACITY, "more than STORM_NOALLOC_MAX_N frequencies in one allocation-free call");
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+    int* flags = reinterpret_cast<int*>(s->scratch);
+    double* partial = reinterpret_cast<double*>(s->scratch + kScratchFlagBytes);
+    const size_t n_int = s->sys.n_int;
+    // the automatic choice of storm_det_batch_device, minus the path that stages step matrices in a buffer of its own
+    const SegPlan plan = n < s->hex_min_n ? plan_segments(s, n, n_int) : SegPlan{};
+    if (plan.n_seg && n * size_t(plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes)
+      fail(STORM_ERR_CAPACITY, "the segment transfer matrices of this call exceed the allocation-free scratch "
+                               "(STORM_NOALLOC_SCRATCH_BYTES): fewer frequencies per call, or longer segments");
+    if (st != s->stream) hip_check(hipStreamWaitEvent(st, s->ready, 0), "hipStreamWaitEvent");
+    hip_check(hipMemsetAsync(flags, 0, 2 * sizeof(int), st), "flags memset");  // the scratch keeps the last call's contents
+    LaunchArgs a = make_args(s, d_freq, n, d_out, st, flags);
+    if (plan.n_seg) {
+      a.out = partial; a.n_seg = plan.n_seg; a.seg_len = plan.seg_len;
+      hip_check(g_launch_seg_product[s->arith][s->scheme](a), "seg_product launch");
+      SystemDev reduced = s->sys;
+      reduced.n_int = size_t(plan.n_seg);
+      hip_check(storm_fast::launch_chain(reduced, s->ell0, d_freq, n, partial, d_out, st), "chain launch");
+      count_launch(s, 2);
+    } else if (n_int == 0) {
+      hip_check(g_launch_fused[s->arith][s->scheme](a), "det_fused launch");
+      count_launch(s);
+    } else {
+      hip_check(g_launch_hex[s->arith][s->scheme](a), "det_hex launch");
+      count_launch(s);
+    }
+    s->stats.det_evals += n;
+    if (!hip_stream) hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
   });
 }
 
