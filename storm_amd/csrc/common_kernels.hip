@@ -94,6 +94,179 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
 }
 
 // ---------------------------------------------------------------------------------------
+// Bracketing on the device (reference src/bracket.rs): the sign-swap filter over the scan values with an ORDERED
+// compaction of the brackets, and the per-bracket state machine of InverseQuadratic::optimize advanced one evaluation
+// per round in device memory, so that a refinement round is "propose -> evaluate -> update" without the abscissae or the
+// discriminants crossing PCIe.  Integer ULP logic on the raw bit patterns like the reference (f64::to_bits).  The host
+// versions of the same functions live in storm_hip.hip; this file is compiled -ffp-contract=off in namespace storm,
+// which is the one the host uses for these kernels in BOTH arithmetic modes (the proposals are the reference's).
+// ---------------------------------------------------------------------------------------
+SDEV bool is_finite(double x) { return (((unsigned long long)__double_as_longlong(x) >> 52) & 0x7ff) != 0x7ff; }
+SDEV bool is_nan(double x) { return x != x; }
+// f64::signum compared for inequality: by sign bit; NaN.signum() is NaN and NaN != anything.
+SDEV bool signum_differs(double a, double b) {
+  if (is_nan(a) || is_nan(b)) return true;
+  return (__double_as_longlong(a) < 0) != (__double_as_longlong(b) < 0);
+}
+
+constexpr int kSwapBlock = 256;  // threads
+constexpr int kSwapPer = 4;      // adjacent pairs per thread
+
+// 0: no sign swap, 1: a bracket, 2: a sign swap with a non-finite end (dropped, raises the "invalid numbers" flag)
+SDEV int pair_kind(const double* __restrict__ det, size_t i) {
+  const double a = det[i], b = det[i + 1];
+  if (!signum_differs(a, b)) return 0;
+  return (is_finite(a) && is_finite(b)) ? 1 : 2;
+}
+
+__global__ __launch_bounds__(kSwapBlock) void swap_count_kernel(const double* __restrict__ det, size_t n,
+                                                                unsigned* __restrict__ block_count, int* __restrict__ flags) {
+  __shared__ unsigned sh[kSwapBlock / 64];
+  const size_t first = ((size_t)blockIdx.x * kSwapBlock + threadIdx.x) * kSwapPer;
+  unsigned cnt = 0;
+  bool invalid = false;
+#pragma unroll
+  for (int j = 0; j < kSwapPer; ++j)
+    if (first + j + 1 < n) {
+      const int k = pair_kind(det, first + j);
+      cnt += (k == 1);
+      invalid = invalid || (k == 2);
+    }
+  if (invalid) atomicOr(flags, 2);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+#pragma unroll
+    for (int w = 0; w < kSwapBlock / 64; ++w) t += sh[w];
+    block_count[blockIdx.x] = t;
+  }
+}
+
+// block_offset[b] = number of brackets before block b (host-side exclusive sum of the block counts).
+__global__ __launch_bounds__(kSwapBlock) void swap_emit_kernel(const double* __restrict__ freq, const double* __restrict__ det,
+                                                               size_t n, const unsigned* __restrict__ block_offset,
+                                                               BracketDev* __restrict__ out, unsigned long long* __restrict__ index_out) {
+  __shared__ unsigned sh[kSwapBlock];
+  const size_t first = ((size_t)blockIdx.x * kSwapBlock + threadIdx.x) * kSwapPer;
+  int kind[kSwapPer];
+  unsigned cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kSwapPer; ++j) {
+    kind[j] = (first + j + 1 < n) ? pair_kind(det, first + j) : 0;
+    cnt += (kind[j] == 1);
+  }
+  sh[threadIdx.x] = cnt;
+  __syncthreads();
+  // exclusive scan over the block's threads (Hillis-Steele, 8 steps)
+  unsigned incl = cnt;
+  for (int d = 1; d < kSwapBlock; d <<= 1) {
+    const unsigned add = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    incl += add;
+    sh[threadIdx.x] = incl;
+    __syncthreads();
+  }
+  size_t at = (size_t)block_offset[blockIdx.x] + (incl - cnt);
+#pragma unroll
+  for (int j = 0; j < kSwapPer; ++j)
+    if (kind[j] == 1) {
+      const size_t i = first + j;
+      BracketDev b;
+      b.lo_x = freq[i]; b.lo_f = det[i]; b.hi_x = freq[i + 1]; b.hi_f = det[i + 1];
+      b.pv_x = 0.0; b.pv_f = 0.0; b.root = 0.0; b.pending = 0.0; b.evals = 0; b.has_prev = 0; b.done = 0;
+      out[at] = b;
+      index_out[at] = i;
+      ++at;
+    }
+}
+
+// evaluate_secant / evaluate_inverse_quadratic at y = 0, src/bracket.rs:73-81 (same association as the host versions)
+SDEV double dev_secant(double ax, double af, double bx, double bf) {
+  const double y = 0.0;
+  return (y - bf) / (af - bf) * ax + (y - af) / (bf - af) * bx;
+}
+SDEV double dev_inverse_quadratic(double ax, double af, double bx, double bf, double cx, double cf) {
+  const double y = 0.0;
+  return (y - bf) * (y - cf) / (af - bf) / (af - cf) * ax + (y - af) * (y - cf) / (bf - af) / (bf - cf) * bx +
+         (y - af) * (y - bf) / (cf - bf) / (cf - af) * cx;
+}
+
+// One round of InverseQuadratic::optimize (src/bracket.rs:172-221) for every bracket: consume the discriminant of the
+// pending abscissa (f_in, null in the first round), then propose the next one.  x_out[k] is what the discriminant
+// kernels evaluate next; a finished bracket re-submits its root (the value is ignored).  live_out counts the brackets
+// that still want an evaluation.  flags: 4 = non-finite discriminant (the reference asserts), 8 = bracket precondition.
+__global__ __launch_bounds__(64) void refine_step_kernel(BracketDev* __restrict__ br, unsigned n, const double* __restrict__ f_in,
+                                                         double* __restrict__ x_out, unsigned long long ulp,
+                                                         unsigned* __restrict__ live_out, int* __restrict__ flags) {
+  const unsigned k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= n) return;
+  BracketDev b = br[k];
+  if (!b.done && f_in != nullptr) {
+    const double nx = b.pending, nf = f_in[k];
+    if (!is_finite(nx) || !is_finite(nf)) {
+      atomicOr(flags, 4);
+      b.done = 1;
+    } else {
+      b.evals += 1;
+      if (!signum_differs(b.hi_f, nf)) { b.pv_x = b.hi_x; b.pv_f = b.hi_f; b.hi_x = nx; b.hi_f = nf; }
+      else { b.pv_x = b.lo_x; b.pv_f = b.lo_f; b.lo_x = nx; b.lo_f = nf; }
+      b.has_prev = 1;
+    }
+  }
+  if (!b.done) {
+    double x;
+    if (!b.has_prev) {
+      x = dev_secant(b.lo_x, b.lo_f, b.hi_x, b.hi_f);
+    } else {
+      x = dev_inverse_quadratic(b.lo_x, b.lo_f, b.hi_x, b.hi_f, b.pv_x, b.pv_f);
+      if (x <= b.lo_x || x >= b.hi_x) x = dev_secant(b.lo_x, b.lo_f, b.hi_x, b.hi_f);
+    }
+    // ensure_maximal_bracket, src/bracket.rs:96-132
+    const double upper = b.hi_x, lower = b.lo_x;
+    if (!(upper > lower) || !is_finite(upper) || !is_finite(lower) || !(upper >= 0.0) || !(lower >= 0.0)) {
+      atomicOr(flags, 8);
+      b.done = 1;
+    } else {
+      const unsigned long long ub = (unsigned long long)__double_as_longlong(upper), lb = (unsigned long long)__double_as_longlong(lower);
+      if (ub - lb <= ulp) {
+        b.done = 1;
+        b.root = x;
+      } else {
+        unsigned long long xb = (unsigned long long)__double_as_longlong(x);
+        if ((ub - lb) <= 2 * ulp) xb = lb + (ub - lb) / 2;
+        else if ((ub < xb) || (ub - xb) < ulp) xb = ub - ulp;
+        else if ((lb > xb) || (xb - lb) < ulp) xb = lb + ulp;
+        b.pending = __longlong_as_double((long long)xb);
+      }
+    }
+  }
+  x_out[k] = b.done ? b.lo_x : b.pending;
+  if (!b.done) atomicAdd(live_out, 1u);
+  br[k] = b;
+}
+
+hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count, int* flags, hipStream_t stream) {
+  if (n < 2) return hipSuccess;
+  swap_count_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(det, n, block_count, flags);
+  return hipGetLastError();
+}
+hipError_t launch_swap_emit(const double* freq, const double* det, size_t n, const unsigned* block_offset, BracketDev* out,
+                            unsigned long long* index_out, hipStream_t stream) {
+  if (n < 2) return hipSuccess;
+  swap_emit_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(freq, det, n, block_offset, out, index_out);
+  return hipGetLastError();
+}
+hipError_t launch_refine_step(BracketDev* br, size_t n, const double* f_in, double* x_out, unsigned long long ulp,
+                              unsigned* live_out, int* flags, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  refine_step_kernel<<<(unsigned)((n + 63) / 64), 64, 0, stream>>>(br, (unsigned)n, f_in, x_out, ulp, live_out, flags);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Eigenvector: forward elimination, one wave per mode.
 // Lane j < 8 owns system column j of the 6x8 band (6 values in registers).  A lone wave issues one instruction
 // (vector OR scalar) per ~4 cycles, so the kernel is shaped by instruction count, not by lanes:

@@ -85,6 +85,9 @@ static hipError_t launch_hex_v(const LaunchArgs& a) {
   int lpf = a.hex_lanes;
   if (lpf != 16 && lpf != 32)
     lpf = hex_cost<ELL0, UNIFORM, 32>(a.n, a.sys.n_int) < hex_cost<ELL0, UNIFORM, 16>(a.n, a.sys.n_int) ? 32 : 16;
+  // (Tried and measured no gain, round 2: sending the whole wave rounds at 16 lanes and the remainder as a second launch
+  // at 32 lanes.  10^5 frequencies are 25000 waves on 2048 slots = 12.2 rounds; the launch takes 12.2 rounds' time, not
+  // 13 -- waves drift apart and the dispatcher refills SIMDs continuously -- so the split only added a launch.)
   return lpf == 32 ? launch_hex_lpf<ELL0, UNIFORM, 32>(a) : launch_hex_lpf<ELL0, UNIFORM, 16>(a);
 }
 template <bool ELL0, bool UNIFORM>

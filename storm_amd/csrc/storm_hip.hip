@@ -259,6 +259,15 @@ struct storm_solver {
   DevBuf<double> d_partials, d_nodes, d_vec_fb, d_det_fb, d_freq_fb;
   DevBuf<unsigned long long> d_growth;
   PinnedBuf h_vec, h_flags, h_growth;
+  // bracketing on the device (common_kernels.hip): bracket states, their grid indices, block counts / offsets of the
+  // ordered compaction, proposed abscissae and their discriminants, live counters per round, error flags
+  DevBuf<BracketDev> d_br;
+  DevBuf<unsigned long long> d_bidx;
+  DevBuf<unsigned> d_bcount, d_live;
+  DevBuf<double> d_bx, d_bf;
+  DevBuf<int> d_bflags;
+  PinnedBuf h_br;
+  int device_brackets = 1;                       // 1 (default): sign-swap filter and refinement state machine on the device
   int segments = 0;                              // 0 auto (FMA build only), -1 off, > 0 forced segment length
   double seg_growth_max = 16777216.0;            // 2^24: larger segment transfer matrices send a mode to the sequential path
   const double* h_freq_last = nullptr;           // the caller's frequencies of the eigenvector chunk in flight
@@ -669,6 +678,88 @@ void refine_all(storm_solver* s, std::vector<BracketState>& br, uint64_t ulp) {
   }
 }
 
+// ---- the same on the device (common_kernels.hip, "Bracketing on the device") ----
+constexpr size_t kMaxRounds = 4096;  // live counters per call (a bracket needs ~5-12 evaluations at 1e-8, < 70 at 1 ULP)
+
+// Pinned staging of the device bracketing: [2 ints: flags][kMaxRounds + 1 live counters][block counts][brackets][indices]
+struct BracketStage {
+  int* flags; unsigned* live; unsigned* counts; BracketDev* br; unsigned long long* idx;
+};
+BracketStage bracket_stage(storm_solver* s, size_t n_blocks, size_t n_br) {
+  size_t bytes = 16 + (kMaxRounds + 2) * sizeof(unsigned);
+  bytes = (bytes + 15) / 16 * 16;
+  const size_t off_counts = bytes;
+  bytes += (n_blocks + 4) * sizeof(unsigned);
+  bytes = (bytes + 15) / 16 * 16;
+  const size_t off_br = bytes;
+  bytes += n_br * sizeof(BracketDev);
+  const size_t off_idx = bytes;
+  bytes += n_br * sizeof(unsigned long long);
+  bytes = std::max(bytes, size_t(256) << 10);  // room for ~2000 brackets from the start: regrowth is rare
+  if ((bytes + 7) / 8 > s->h_br.cap && s->h_br.p)  // copies from / to the old block may still be in flight
+    hip_check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+  s->h_br.reserve((bytes + 7) / 8);
+  char* base = reinterpret_cast<char*>(s->h_br.p);
+  return BracketStage{reinterpret_cast<int*>(base), reinterpret_cast<unsigned*>(base + 16), reinterpret_cast<unsigned*>(base + off_counts),
+                      reinterpret_cast<BracketDev*>(base + off_br), reinterpret_cast<unsigned long long*>(base + off_idx)};
+}
+
+void raise_bracket_flags(int flags) {
+  if (flags & 8) fail(STORM_ERR_BRACKET, "bracket must satisfy 0 <= lower < upper < inf");
+  if (flags & 4) fail(STORM_ERR_NON_FINITE, "non-finite discriminant during bracket refinement");
+}
+
+// InverseQuadratic::optimize on the n brackets in s->d_br, all of them advancing one evaluation per round; nothing but
+// the live counters crosses PCIe between rounds.  `stage` must come from bracket_stage(s, ., >= n).
+void refine_device(storm_solver* s, size_t n, uint64_t ulp, const BracketStage& stage) {
+  if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
+  if (!(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
+  if (n == 0) return;
+  hipStream_t st = s->stream;
+  s->d_bx.reserve(n, st); s->d_bf.reserve(n, st);
+  s->d_live.reserve(kMaxRounds + 2, st);
+  s->d_bflags.reserve(2, st);
+  hip_check(hipMemsetAsync(s->d_live.p, 0, (kMaxRounds + 2) * sizeof(unsigned), st), "live memset");
+  const uint64_t evals_before = s->stats.det_evals;
+  // rounds between two looks at the live counters: a round costs ~30 us on the segment path (a wasted one is cheap),
+  // ~0.5 ms on the ordered-product path (never waste one)
+  const size_t batch = plan_segments(s, n, s->sys.n_int).n_seg ? 3 : 1;
+  hip_check(storm::launch_refine_step(s->d_br.p, n, nullptr, s->d_bx.p, ulp, s->d_live.p, s->d_bflags.p, st), "refine_step launch");
+  count_launch(s);
+  size_t round = 0;  // live[r] = brackets that want evaluation r + 1
+  for (;;) {
+    // (no look at the counters before the first batch: a bracket that is converged before its first evaluation is rare)
+    if (round + batch > kMaxRounds) fail(STORM_ERR_BRACKET, "bracket refinement did not converge");
+    for (size_t b = 0; b < batch; ++b) {
+      det_device(s, s->d_bx.p, n, s->d_bf.p, st);
+      hip_check(storm::launch_refine_step(s->d_br.p, n, s->d_bf.p, s->d_bx.p, ulp, s->d_live.p + round + 1, s->d_bflags.p, st),
+                "refine_step launch");
+      count_launch(s);
+      ++round;
+    }
+    hip_check(hipMemcpyAsync(stage.live, s->d_live.p, (round + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st), "live D2H");
+    hip_check(hipMemcpyAsync(stage.flags, s->d_bflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+    check_flags(s);  // synchronises; singular stage matrices
+    raise_bracket_flags(*stage.flags);
+    if (stage.live[round] == 0) break;
+  }
+  // counters as the host state machine keeps them: evaluations that a live bracket consumed, rounds that had one
+  size_t rounds = 0;
+  uint64_t evals = 0;
+  for (size_t r = 0; r < round; ++r) { rounds += stage.live[r] > 0; evals += stage.live[r]; }
+  s->stats.det_evals = evals_before + evals;
+  s->stats.refine_evals += evals;
+  s->stats.refine_rounds += rounds;
+}
+
+void download_brackets(storm_solver* s, size_t n, const BracketStage& stage, bool with_index) {
+  if (n == 0) return;
+  hip_check(hipMemcpyAsync(stage.br, s->d_br.p, n * sizeof(BracketDev), hipMemcpyDeviceToHost, s->stream), "brackets D2H");
+  if (with_index)
+    hip_check(hipMemcpyAsync(stage.idx, s->d_bidx.p, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream), "index D2H");
+  sync_stream(s->stream, s->sync_marker);
+}
+
 // ---- eigenvectors: shared by storm_eigenvector_batch and storm_modes_batch ----
 // Sizes the staging buffers; returns the number of modes processed per chunk.
 size_t eigen_reserve(storm_solver* s, size_t n) {
@@ -967,6 +1058,8 @@ void storm_solver_destroy(storm_solver* s) {
   s->d_upper.release(); s->d_vec.release(); s->d_swaps.release(); s->d_flags.release(); s->h_vec.release(); s->h_flags.release();
   s->d_partials.release(); s->d_nodes.release(); s->d_vec_fb.release(); s->d_det_fb.release(); s->d_freq_fb.release();
   s->d_growth.release(); s->h_growth.release();
+  s->d_br.release(); s->d_bidx.release(); s->d_bcount.release(); s->d_live.release(); s->d_bx.release(); s->d_bf.release();
+  s->d_bflags.release(); s->h_br.release();
   (void)hipSetDevice(prev);
   delete s;
 }
@@ -989,6 +1082,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
       s->arith = int(value);
     } else if (k == "profile") {
       s->profile = value != 0;
+    } else if (k == "device_brackets") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "device_brackets must be 0 (host state machine) or 1");
+      s->device_brackets = int(value);
     } else if (k == "segments") {
       if (value < -1 || value > (1 << 20)) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be -1 (off), 0 (auto) or a segment length");
       s->segments = int(value);
@@ -1122,11 +1218,61 @@ static void filter_sign_swaps(const double* freq, const double* dets, size_t n, 
   }
 }
 
+// scan_and_optimize with the filter, the compaction and the refinement on the device: the grid goes up once, the
+// brackets come down once (plus the scan values if the caller wants them).
+static void scan_on_device(storm_solver* s, const double* freq, size_t n, bool refine, uint64_t ulp, storm_bracket* out,
+                           size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (refine && ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
+  if (refine && !(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
+  if (n == 0) return;
+  hipStream_t st = s->stream;
+  s->d_freq.reserve(n, st); s->d_det.reserve(n, st);
+  hip_check(hipMemcpyAsync(s->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+  det_device(s, s->d_freq.p, n, s->d_det.p, st);
+  if (det_out) hip_check(hipMemcpyAsync(det_out, s->d_det.p, n * sizeof(double), hipMemcpyDeviceToHost, st), "det D2H");
+  const size_t nb = swap_blocks(n);
+  s->d_bcount.reserve(nb + 4, st);
+  s->d_bflags.reserve(2, st);
+  hip_check(hipMemsetAsync(s->d_bflags.p, 0, 2 * sizeof(int), st), "flags memset");
+  hip_check(storm::launch_swap_count(s->d_det.p, n, s->d_bcount.p, s->d_bflags.p, st), "swap_count launch");
+  BracketStage stage = bracket_stage(s, nb, 0);
+  if (nb) hip_check(hipMemcpyAsync(stage.counts, s->d_bcount.p, nb * sizeof(unsigned), hipMemcpyDeviceToHost, st), "counts D2H");
+  hip_check(hipMemcpyAsync(stage.flags, s->d_bflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+  check_flags(s);  // synchronises; singular stage matrices
+  count_launch(s);
+  size_t total = 0;
+  for (size_t b = 0; b < nb; ++b) { const unsigned c = stage.counts[b]; stage.counts[b] = unsigned(total); total += c; }
+  if (had_invalid) *had_invalid = (*stage.flags & 2) ? 1 : 0;
+  *n_out = total;
+  if (total > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+  if (total == 0) return;
+  if (total > (size_t(1) << 31)) fail(STORM_ERR_CAPACITY, "too many brackets");
+  s->d_br.reserve(total, st); s->d_bidx.reserve(total, st);
+  hip_check(hipMemcpyAsync(s->d_bcount.p, stage.counts, nb * sizeof(unsigned), hipMemcpyHostToDevice, st), "offsets H2D");
+  hip_check(storm::launch_swap_emit(s->d_freq.p, s->d_det.p, n, s->d_bcount.p, s->d_br.p, s->d_bidx.p, st), "swap_emit launch");
+  count_launch(s);
+  stage = bracket_stage(s, nb, total);  // (may move the pinned block: the offsets upload must have been consumed)
+  if (refine) {
+    refine_device(s, total, ulp, stage);
+  }
+  download_brackets(s, total, stage, true);
+  for (size_t k = 0; k < total; ++k) {
+    const BracketDev& b = stage.br[k];
+    if (!std::isfinite(b.lo_x) || !std::isfinite(b.hi_x)) fail(STORM_ERR_BRACKET, "non-finite scan frequency");
+    out[k] = storm_bracket{b.lo_x, b.lo_f, b.hi_x, b.hi_f, refine ? b.root : std::numeric_limits<double>::quiet_NaN(), b.evals};
+    if (index_out) index_out[k] = stage.idx[k];
+  }
+}
+
 static void scan_impl(storm_solver* s, const double* freq, size_t n, bool refine, uint64_t ulp, storm_bracket* out,
                       size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
   if (!s || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
   std::lock_guard<std::mutex> lock(s->mu);
   DeviceGuard g(s->device);
+  if (s->device_brackets) {
+    scan_on_device(s, freq, n, refine, ulp, out, cap, n_out, had_invalid, det_out, index_out);
+    return;
+  }
   std::vector<double> local;
   double* dets = det_out;
   if (!dets) { local.resize(n); dets = local.data(); }
@@ -1178,6 +1324,24 @@ int storm_optimize_brackets(storm_solver* s, storm_bracket* brackets, size_t n, 
       if (sign_of(b.lo_f) == sign_of(b.hi_f)) fail(STORM_ERR_BRACKET, "bracket end values must differ in sign");
       br[k].lower = Pt{b.lo_x, b.lo_f};
       br[k].upper = Pt{b.hi_x, b.hi_f};
+    }
+    if (s->device_brackets) {
+      BracketStage stage = bracket_stage(s, 0, n);
+      for (size_t k = 0; k < n; ++k) {
+        BracketDev d{};
+        d.lo_x = br[k].lower.x; d.lo_f = br[k].lower.f; d.hi_x = br[k].upper.x; d.hi_f = br[k].upper.f;
+        stage.br[k] = d;
+      }
+      s->d_br.reserve(n, s->stream);
+      s->d_bflags.reserve(2, s->stream);
+      hip_check(hipMemsetAsync(s->d_bflags.p, 0, 2 * sizeof(int), s->stream), "flags memset");
+      hip_check(hipMemcpyAsync(s->d_br.p, stage.br, n * sizeof(BracketDev), hipMemcpyHostToDevice, s->stream), "brackets H2D");
+      refine_device(s, n, ulp, stage);
+      download_brackets(s, n, stage, false);
+      for (size_t k = 0; k < n; ++k)
+        brackets[k] = storm_bracket{stage.br[k].lo_x, stage.br[k].lo_f, stage.br[k].hi_x, stage.br[k].hi_f, stage.br[k].root,
+                                    stage.br[k].evals};
+      return;
     }
     refine_all(s, br, ulp);
     for (size_t k = 0; k < n; ++k)
