@@ -268,6 +268,32 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* sweep, size_t n_problems, s
                                         const double* freq, const int64_t* m, const storm_metric_desc* metrics,
                                         double* const* out);
 
+/* ---- One scan over several GPUs of a node, inside the library ----
+ *
+ * The reference's rayon map over the scan frequencies (src/dynamic_interface.rs:125-127) is independent per frequency,
+ * so a storm_multi runs it on several devices from ONE process: one storm_solver per listed device (the coefficient
+ * planes are replicated), one host thread per device inside a call.  storm_multi_scan_and_optimize = ErasedSolver::
+ * scan_and_optimize (src/dynamic_interface.rs:116-160): device k evaluates the contiguous slice
+ * [k*ceil(n/n_dev), (k+1)*ceil(n/n_dev)) plus ONE halo point, so every adjacent pair is owned by exactly one device; the
+ * sign-swap brackets (a few KB) are gathered in host memory in ascending order -- the reference's single global
+ * filter_sign_swap order (src/bracket.rs:236-250); no collective library is involved inside one process -- and dealt out
+ * cyclically by global bracket index for the refinement (src/dynamic_interface.rs:139-151), so that a slice dense in
+ * modes does not serialise on the device that scanned it.  storm_multi_eigenvector_batch deals the modes the same way.
+ * Results are bit-identical to one storm_solver on one device (every evaluation runs the same kernels).  `devices` may
+ * list a device more than once (it then runs several slices; used to test the logic on one GPU).  Options are
+ * forwarded to every solver.  One process per GPU over RCCL instead: storm_amd/distributed.py (same split, same deal). */
+typedef struct storm_multi storm_multi;
+int storm_multi_create(const storm_system_desc* desc, const int* devices, size_t n_dev, storm_multi** out);
+void storm_multi_destroy(storm_multi* multi);
+size_t storm_multi_devices(const storm_multi* multi);
+int storm_multi_set_option(storm_multi* multi, const char* key, int64_t value);
+int storm_multi_scan_and_optimize(storm_multi* multi, const double* freq, size_t n, uint64_t ulp, storm_bracket* out,
+                                  size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out);
+int storm_multi_eigenvector_batch(storm_multi* multi, const double* freq, size_t n, double* det_out, double* vec_out);
+/* The split itself (pure index arithmetic, no device): the grid points [*lo, *hi) that part k of n_parts owns; the
+ * part evaluates [*lo, min(*hi + 1, n)). */
+void storm_shard_bounds(size_t n, size_t n_parts, size_t k, size_t* lo, size_t* hi);
+
 /* ---- Memory cache (no counterpart in the reference) ----
  * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
  * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent
@@ -288,6 +314,7 @@ typedef struct {
   uint64_t det_evals, refine_evals, refine_rounds, eigenvectors, launches, segment_fallbacks;
 } storm_stats;
 int storm_solver_stats(storm_solver* solver, storm_stats* out, int reset);
+int storm_multi_stats(storm_multi* multi, storm_stats* out, int reset);   /* summed over the devices (refine_rounds: max) */
 
 /* Per-kernel device time, measured with HIP events recorded on the launch stream around every
  * launch while option "profile" is 1.  ms_out / launches_out have STORM_KERNEL_KINDS entries. */

@@ -1671,6 +1671,181 @@ int storm_modes_batch(storm_solver* s, storm_postproc* p, const double* freq, si
 }  // extern "C"
 
 // =====================================================================================================================
+// storm_multi: one scan over several devices from one process; see include/storm_hip.h.
+// =====================================================================================================================
+struct storm_multi {
+  std::vector<storm_solver*> solvers;
+  std::vector<int> devices;
+  std::mutex mu;
+};
+
+namespace {
+// Runs job(k) for k < n on n host threads (the caller's thread takes k = 0); the first failure wins and its message
+// becomes the caller's storm_last_error().
+template <class Job>
+void on_every_device(size_t n, Job&& job) {
+  std::vector<int> rc(n, STORM_OK);
+  std::vector<std::string> msg(n);
+  auto run = [&](size_t k) {
+    rc[k] = job(k);
+    if (rc[k] != STORM_OK) msg[k] = g_error;  // (thread-local: read on the thread that failed)
+  };
+  std::vector<std::thread> pool;
+  for (size_t k = 1; k < n; ++k) pool.emplace_back(run, k);
+  run(0);
+  for (auto& th : pool) th.join();
+  for (size_t k = 0; k < n; ++k)
+    if (rc[k] != STORM_OK) fail(rc[k], "device " + std::to_string(k) + ": " + msg[k]);
+}
+}  // namespace
+
+extern "C" {
+
+void storm_shard_bounds(size_t n, size_t n_parts, size_t k, size_t* lo, size_t* hi) {
+  const size_t per = n_parts ? (n + n_parts - 1) / n_parts : n;
+  const size_t a = std::min(n, k * per), b = std::min(n, a + per);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+
+int storm_multi_create(const storm_system_desc* desc, const int* devices, size_t n_dev, storm_multi** out) {
+  if (out) *out = nullptr;
+  storm_multi* q = nullptr;
+  int rc = guarded([&] {
+    if (!desc || !devices || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_dev == 0 || n_dev > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "a storm_multi needs 1..1024 devices");
+    int ndev = 0;
+    hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    for (size_t k = 0; k < n_dev; ++k)
+      if (devices[k] < 0 || devices[k] >= ndev) fail(STORM_ERR_INVALID_ARGUMENT, "no such HIP device: " + std::to_string(devices[k]));
+    q = new storm_multi();
+    q->devices.assign(devices, devices + n_dev);
+    q->solvers.assign(n_dev, nullptr);
+    on_every_device(n_dev, [&](size_t k) {
+      int prev = 0;
+      if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(q->devices[k]) != hipSuccess) { g_error = "hipSetDevice failed"; return int(STORM_ERR_HIP); }
+      const int r = storm_solver_create(desc, &q->solvers[k]);
+      (void)hipSetDevice(prev);
+      return r;
+    });
+    *out = q;
+  });
+  if (rc != STORM_OK && q) { storm_multi_destroy(q); if (out) *out = nullptr; }
+  return rc;
+}
+
+void storm_multi_destroy(storm_multi* q) {
+  if (!q) return;
+  for (storm_solver* s : q->solvers) storm_solver_destroy(s);
+  delete q;
+}
+
+size_t storm_multi_devices(const storm_multi* q) { return q ? q->solvers.size() : 0; }
+
+int storm_multi_set_option(storm_multi* q, const char* key, int64_t value) {
+  return guarded([&] {
+    if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    for (storm_solver* s : q->solvers) {
+      const int rc = storm_solver_set_option(s, key, value);
+      if (rc != STORM_OK) fail(rc, g_error);
+    }
+  });
+}
+
+int storm_multi_stats(storm_multi* q, storm_stats* out, int reset) {
+  return guarded([&] {
+    if (!q || !out) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    *out = storm_stats{};
+    for (storm_solver* s : q->solvers) {
+      storm_stats one{};
+      const int rc = storm_solver_stats(s, &one, reset);
+      if (rc != STORM_OK) fail(rc, g_error);
+      out->det_evals += one.det_evals; out->refine_evals += one.refine_evals; out->eigenvectors += one.eigenvectors;
+      out->launches += one.launches; out->segment_fallbacks += one.segment_fallbacks;
+      out->refine_rounds = std::max(out->refine_rounds, one.refine_rounds);  // the devices' rounds run side by side
+    }
+  });
+}
+
+int storm_multi_scan_and_optimize(storm_multi* q, const double* freq, size_t n, uint64_t ulp, storm_bracket* out, size_t cap,
+                                  size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (n_out) *n_out = 0;
+  if (had_invalid) *had_invalid = 0;
+  return guarded([&] {
+    if (!q || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
+    std::lock_guard<std::mutex> lock(q->mu);
+    const size_t D = q->solvers.size();
+    // 1. every device scans its slice (+1 halo point) and filters its own adjacent pairs
+    struct Part { size_t lo = 0; std::vector<storm_bracket> br; std::vector<uint64_t> idx; std::vector<double> det; int invalid = 0; };
+    std::vector<Part> parts(D);
+    on_every_device(D, [&](size_t k) {
+      Part& p = parts[k];
+      size_t lo, hi;
+      storm_shard_bounds(n, D, k, &lo, &hi);
+      p.lo = lo;
+      const size_t m = std::min(hi + 1, n) - lo;  // with the halo
+      if (hi == lo) return int(STORM_OK);
+      p.br.resize(m); p.idx.resize(m);
+      if (det_out) p.det.resize(m);
+      size_t found = 0;
+      const int rc = storm_scan_brackets(q->solvers[k], freq + lo, m, p.br.data(), m, &found, &p.invalid,
+                                         det_out ? p.det.data() : nullptr, p.idx.data());
+      p.br.resize(found); p.idx.resize(found);
+      if (rc == STORM_OK && det_out) std::memcpy(det_out + lo, p.det.data(), (hi - lo) * sizeof(double));  // owned points only
+      return rc;
+    });
+    // 2. the gather: slices are contiguous, so rank order is ascending bracket order
+    std::vector<storm_bracket> all;
+    std::vector<uint64_t> idx;
+    int invalid = 0;
+    for (const Part& p : parts) {
+      invalid |= p.invalid;
+      for (size_t j = 0; j < p.br.size(); ++j) { all.push_back(p.br[j]); idx.push_back(p.idx[j] + p.lo); }
+    }
+    if (had_invalid) *had_invalid = invalid;
+    *n_out = all.size();
+    if (all.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+    // 3. the deal: bracket j goes to device j mod D
+    std::vector<std::vector<storm_bracket>> share(D);
+    for (size_t j = 0; j < all.size(); ++j) share[j % D].push_back(all[j]);
+    on_every_device(D, [&](size_t k) {
+      return share[k].empty() ? int(STORM_OK) : storm_optimize_brackets(q->solvers[k], share[k].data(), share[k].size(), ulp);
+    });
+    for (size_t j = 0; j < all.size(); ++j) {
+      out[j] = share[j % D][j / D];
+      if (index_out) index_out[j] = idx[j];
+    }
+  });
+}
+
+int storm_multi_eigenvector_batch(storm_multi* q, const double* freq, size_t n, double* det_out, double* vec_out) {
+  return guarded([&] {
+    if (!q || (n && (!freq || !vec_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(q->mu);
+    const size_t D = q->solvers.size(), len = (q->solvers[0]->sys.n_int + 1) * 4;
+    on_every_device(D, [&](size_t k) {
+      std::vector<double> f, d, v;
+      for (size_t j = k; j < n; j += D) f.push_back(freq[j]);
+      if (f.empty()) return int(STORM_OK);
+      d.resize(f.size()); v.resize(f.size() * len);
+      const int rc = storm_eigenvector_batch(q->solvers[k], f.data(), f.size(), d.data(), v.data());
+      if (rc != STORM_OK) return rc;
+      for (size_t i = 0, j = k; j < n; j += D, ++i) {
+        std::memcpy(vec_out + j * len, v.data() + i * len, len * sizeof(double));
+        if (det_out) det_out[j] = d[i];
+      }
+      return int(STORM_OK);
+    });
+  });
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
 // storm_sweep: several systems per launch.
 //
 // The reference's batch inputs sweep ~10^3 rotation rates x 8 (ell, m) systems with scans of only 100-300 frequencies

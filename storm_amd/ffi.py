@@ -65,7 +65,9 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
            "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
            "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices",
-           "storm_sweep_coupling_matrices_batch", "storm_scan_brackets", "storm_optimize_brackets", "storm_det_batch_device_noalloc"]
+           "storm_sweep_coupling_matrices_batch", "storm_scan_brackets", "storm_optimize_brackets", "storm_det_batch_device_noalloc", "storm_multi_create", "storm_multi_destroy",
+           "storm_multi_devices", "storm_multi_set_option", "storm_multi_stats", "storm_multi_scan_and_optimize",
+           "storm_multi_eigenvector_batch", "storm_shard_bounds"]
 
 _lib = None
 
@@ -115,6 +117,18 @@ def load_library():
     L.storm_memory_cache_stats.restype = None
     L.storm_postproc_last_kernel_ms.restype = C.c_double
     L.storm_postproc_last_kernel_ms.argtypes = [C.c_void_p]
+    L.storm_multi_create.argtypes = [C.POINTER(SystemDesc), C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.storm_multi_destroy.argtypes = [C.c_void_p]
+    L.storm_multi_destroy.restype = None
+    L.storm_multi_devices.restype = C.c_size_t
+    L.storm_multi_devices.argtypes = [C.c_void_p]
+    L.storm_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.storm_multi_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_int]
+    L.storm_multi_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_uint64, C.POINTER(Bracket), C.c_size_t,
+                                                C.POINTER(C.c_size_t), C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
+    L.storm_multi_eigenvector_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, _dp]
+    L.storm_shard_bounds.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.storm_shard_bounds.restype = None
     _sp = C.POINTER(C.c_size_t)
     L.storm_sweep_create.argtypes = [C.POINTER(SystemDesc), C.c_size_t, C.POINTER(C.c_void_p)]
     L.storm_sweep_destroy.argtypes = [C.c_void_p]
@@ -313,6 +327,68 @@ class HipSolver:
         out["det"] = dets
         out["vec"] = vec
         return out
+
+
+class HipMulti:
+    """One storm_multi handle: a scan over several devices of the node from this process (devices may repeat)."""
+
+    def __init__(self, scheme, ell, m, system, n_int, p, devices):
+        L = load_library()
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        arrs = {k: _f64(system[k]) for k in ("u", "v_gamma", "a_star", "c1", "rot", "delta_over_x")}
+        d = SystemDesc(scheme, ell, m, n_int, p, *[_p(arrs[k]) for k in ("u", "v_gamma", "a_star", "c1", "rot", "delta_over_x")],
+                       float(system["inner_c1"]), float(system["inner_rot"]), float(system["outer_u"]))
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(L.storm_multi_create(C.byref(d), devs, len(devices), C.byref(h)))
+        self._h = h
+        self.n_int, self.p, self.scheme, self.n_dev = n_int, p, scheme, len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().storm_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _check(load_library().storm_multi_set_option(self._h, key.encode(), int(value)))
+
+    def stats(self, reset=False):
+        s = Stats()
+        _check(load_library().storm_multi_stats(self._h, C.byref(s), 1 if reset else 0))
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def scan_and_optimize(self, freqs, ulp, cap=None):
+        f = _f64(freqs)
+        cap = max(1, f.size) if cap is None else cap
+        out = (Bracket * max(cap, 1))()
+        idx = (C.c_uint64 * max(cap, 1))()
+        dets = np.empty(f.size)
+        n_out, inv = C.c_size_t(0), C.c_int(0)
+        _check(load_library().storm_multi_scan_and_optimize(self._h, _p(f), f.size, ulp, out, cap, C.byref(n_out),
+                                                            C.byref(inv), _p(dets), idx))
+        res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
+                    index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
+        return res, dets, bool(inv.value)
+
+    def eigenvector(self, freqs):
+        f = _f64(np.atleast_1d(freqs))
+        dets = np.empty(f.size)
+        vec = np.empty((f.size, (self.n_int + 1) * 4))
+        _check(load_library().storm_multi_eigenvector_batch(self._h, _p(f), f.size, _p(dets), _p(vec)))
+        return dets, vec
+
+
+def shard_bounds(n, n_parts, k):
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    load_library().storm_shard_bounds(n, n_parts, k, C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
 
 
 def _offsets(lists):

@@ -161,3 +161,25 @@ def test_host_perturb_structure_matches_oracle(oracle, oracle_models, golden_dir
         assert np.all(a["alpha"][1:] > 0) and np.all(a["beta"][1:] < 0)     # P0 expands, P2 flattens the poles
     a1, a2 = hm.perturb_structure(0.01), hm.perturb_structure(0.02)
     np.testing.assert_allclose(a2["alpha"], 4.0 * a1["alpha"], rtol=1e-13)   # quadratic in the rotation rate
+
+
+def test_shard_bounds_of_the_library_cover_every_pair_once():
+    """storm_shard_bounds (the split storm_multi uses; pure index arithmetic, runs without a GPU) equals the split of
+    storm_amd/distributed.py, and with one halo point every adjacent pair of grid points belongs to exactly one part."""
+    from storm_amd import ffi, distributed as D
+    for n in (0, 1, 2, 7, 64, 1000, 100001):
+        for parts in (1, 2, 3, 8, 13):
+            pairs = []
+            for k in range(parts):
+                lo, hi = ffi.shard_bounds(n, parts, k)
+                assert (lo, hi) == D.shard_bounds(n, parts, k)
+                assert 0 <= lo <= hi <= n
+                if n <= 1000:
+                    pairs += [(i, i + 1) for i in range(lo, min(hi + 1, n) - 1)]
+            if n <= 1000:
+                assert pairs == [(i, i + 1) for i in range(max(0, n - 1))]
+    # the deal of the brackets: cyclic by global index, every bracket exactly once
+    for n_br in (0, 1, 5, 22, 163):
+        for parts in (1, 2, 3, 8):
+            dealt = sorted(sum((D.deal(n_br, parts, k) for k in range(parts)), []))
+            assert dealt == list(range(n_br))
