@@ -44,6 +44,36 @@ SDEV M4 m4_mul(const M4& a, const M4& b) {
   return c;
 }
 
+#ifdef STORM_FAST_BUILD
+// FMA build: products with the point matrices A_j = (dx/x) A(x_j, omega), whose entries (2,0), (2,1) and (0,3) are
+// structurally zero (Rotating1D::eval / add_frequency never write them, src/system/adiabatic.rs:78-152).  ZA / ZB: bit
+// c*4+r set = entry (r, c) of the left / right factor is a structural zero; the products with them are skipped (the parity
+// build keeps them: 0*x is not 0 for x = inf/NaN, and x + 0 is not x for x = -0).
+constexpr unsigned kPointMatrixZeros = (1u << (0 * 4 + 2)) | (1u << (1 * 4 + 2)) | (1u << (3 * 4 + 0));
+template <unsigned ZA, unsigned ZB>
+SDEV M4 m4_mul_sparse(const M4& a, const M4& b) {
+  M4 c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = 0.0;
+      bool first = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool zero = ((ZA >> (k * 4 + r)) & 1u) || ((ZB >> (j * 4 + k)) & 1u);
+        if (!zero) {
+          v = first ? a.v[k * 4 + r] * b.v[j * 4 + k] : a.v[k * 4 + r] * b.v[j * 4 + k] + v;
+          first = false;
+        }
+      }
+      c.v[j * 4 + r] = v;
+    }
+  }
+  return c;
+}
+#endif
+
 SDEV M4 m4_add(const M4& a, const M4& b) {
   M4 c;
 #pragma unroll
@@ -91,7 +121,49 @@ SDEV M4 m4_minus_eye(const M4& a) {  // a - eye
 
 // Cofactor inverse.  `ok` is false when det == 0 (the reference would panic on
 // try_inverse().unwrap()); the caller turns that into a NaN result + error flag.
+#ifdef STORM_FAST_BUILD
+// FMA build: the same adjugate inverse, evaluated through the twelve 2x2 sub-determinants of the row pairs (0,1) and (2,3)
+// (Laplace expansion; each 3x3 cofactor of the reference's formula is a 3-term combination of them), ~100 instructions
+// instead of ~210.  Re-associates the cofactors, so it is not offered in the parity build.  Returns SCALE * a^-1 (the factor
+// goes into the reciprocal of the determinant).
+template <int SCALE = 1>
+SDEV M4 m4_inverse_fast(const M4& a, bool& ok) {
+  auto e = [&](int r, int c) { return a.v[c * 4 + r]; };
+  const double s0 = e(0, 0) * e(1, 1) - e(1, 0) * e(0, 1), s1 = e(0, 0) * e(1, 2) - e(1, 0) * e(0, 2);
+  const double s2 = e(0, 0) * e(1, 3) - e(1, 0) * e(0, 3), s3 = e(0, 1) * e(1, 2) - e(1, 1) * e(0, 2);
+  const double s4 = e(0, 1) * e(1, 3) - e(1, 1) * e(0, 3), s5 = e(0, 2) * e(1, 3) - e(1, 2) * e(0, 3);
+  const double c5 = e(2, 2) * e(3, 3) - e(3, 2) * e(2, 3), c4 = e(2, 1) * e(3, 3) - e(3, 1) * e(2, 3);
+  const double c3 = e(2, 1) * e(3, 2) - e(3, 1) * e(2, 2), c2 = e(2, 0) * e(3, 3) - e(3, 0) * e(2, 3);
+  const double c1 = e(2, 0) * e(3, 2) - e(3, 0) * e(2, 2), c0 = e(2, 0) * e(3, 1) - e(3, 0) * e(2, 1);
+  const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+  ok = ok && (det != 0.0);
+  const double q = double(SCALE) / det;
+  M4 o;
+  auto put = [&](int r, int c, double v) { o.v[c * 4 + r] = v * q; };
+  put(0, 0, e(1, 1) * c5 - e(1, 2) * c4 + e(1, 3) * c3);
+  put(0, 1, -e(0, 1) * c5 + e(0, 2) * c4 - e(0, 3) * c3);
+  put(0, 2, e(3, 1) * s5 - e(3, 2) * s4 + e(3, 3) * s3);
+  put(0, 3, -e(2, 1) * s5 + e(2, 2) * s4 - e(2, 3) * s3);
+  put(1, 0, -e(1, 0) * c5 + e(1, 2) * c2 - e(1, 3) * c1);
+  put(1, 1, e(0, 0) * c5 - e(0, 2) * c2 + e(0, 3) * c1);
+  put(1, 2, -e(3, 0) * s5 + e(3, 2) * s2 - e(3, 3) * s1);
+  put(1, 3, e(2, 0) * s5 - e(2, 2) * s2 + e(2, 3) * s1);
+  put(2, 0, e(1, 0) * c4 - e(1, 1) * c2 + e(1, 3) * c0);
+  put(2, 1, -e(0, 0) * c4 + e(0, 1) * c2 - e(0, 3) * c0);
+  put(2, 2, e(3, 0) * s4 - e(3, 1) * s2 + e(3, 3) * s0);
+  put(2, 3, -e(2, 0) * s4 + e(2, 1) * s2 - e(2, 3) * s0);
+  put(3, 0, -e(1, 0) * c3 + e(1, 1) * c1 - e(1, 2) * c0);
+  put(3, 1, e(0, 0) * c3 - e(0, 1) * c1 + e(0, 2) * c0);
+  put(3, 2, -e(3, 0) * s3 + e(3, 1) * s1 - e(3, 2) * s0);
+  put(3, 3, e(2, 0) * s3 - e(2, 1) * s1 + e(2, 2) * s0);
+  return o;
+}
+#endif
+
 SDEV M4 m4_inverse(const M4& a, bool& ok) {
+#ifdef STORM_FAST_BUILD
+  return m4_inverse_fast<1>(a, ok);
+#endif
   const double* m = a.v;
   M4 o;
   o.v[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +

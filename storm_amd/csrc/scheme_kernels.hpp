@@ -143,6 +143,9 @@ SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
 // Magnus 2/4/6 need just over 256 registers when left alone; capping them at 256 buys a second wave
 // per SIMD (better issue utilisation, phase-B latency hidden behind the other wave's phase A).
 __host__ __device__ constexpr int hex_min_waves(int scheme) {
+#ifdef STORM_FAST_BUILD
+  if (scheme == kColloc4) return 3;  // FMA build: 172 registers left alone, 168 buy the third wave per SIMD
+#endif
   return scheme == kMagnus2 ? 2 : 1;
 }
 
@@ -261,6 +264,82 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
     for (int k = 0; k < 16; ++k) a.v[k] = lds[g * kGroup + k];
     constexpr unsigned long long kMask = LPF == 64 ? ~0ULL : ((1ULL << (LPF & 63)) - 1ULL);
     const bool group_ok = ((bad >> (g * LPF)) & kMask) == 0;
+    const double det = close_determinant<ELL0>(s, f, a);
+    det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
+    if (!group_ok) atomicOr(flags, 1);
+  }
+}
+
+// Column-owner variant ("det_col"): 4 lanes per frequency, 16 frequencies per wave.  Phase A as in det_hex (lane q builds the
+// step matrix of interval 4t+q and parks it row-major in LDS); in phase B lane c owns COLUMN c of the running product and
+// reads every step matrix whole from LDS (all four lanes of a group read the same addresses: broadcast), so the ordered
+// product needs no cross-lane traffic at all: 16 multiply-adds per step and lane, against det_hex's 4 multiply-adds + 8 DPP
+// moves per step and lane for a quarter of the product -- 64 instead of 192 VALU instructions per evaluation spent on the
+// 112-flop product (the kernels are VALU-issue bound: rocprofv3 SQ_ACTIVE_INST_VALU is 94-98 % of the launch).  A column of
+// L*acc is evaluated term by term in the reference's gemm order, so the bits are the same.  It has a quarter of det_hex's
+// waves, each four times as long: the launcher uses it for whole wave rounds of large batches and sends the remainder
+// through det_hex (launch_hex in scheme_tu.hip).
+constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
+
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_col_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+                                                                           double* __restrict__ det_out, int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) double lds[16 * kColGroup];
+  const int tid = threadIdx.x;
+  const int g = tid >> 2;  // frequency within the wave
+  const int q = tid & 3;   // interval within the round (phase A), column of the product (phase B)
+  const size_t t = (size_t)blockIdx.x * 16 + g;
+  const double f = freq[t < n ? t : n - 1];
+  const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
+  bool ok = true;
+  double col[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) col[r] = (r == q) ? 1.0 : 0.0;
+  const size_t n_int = s.n_int;
+  double* __restrict__ mine = lds + g * kColGroup + q * kHexLaneStride;
+  const double* __restrict__ mats = lds + g * kColGroup;
+  for (size_t i0 = 0; i0 < n_int; i0 += 4) {
+    // rows are padded past n_int with copies of the last interval, so no clamping is needed
+    const M4 l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + q, f, ut, ok);
+    __syncthreads();  // previous round's matrices have been consumed
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {  // row-major: row rr = {L(rr,0..3)}
+      *reinterpret_cast<double2*>(mine + rr * 4) = make_double2(l.v[0 * 4 + rr], l.v[1 * 4 + rr]);
+      *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
+    }
+    __syncthreads();
+    double2 m[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) m[k][p] = *reinterpret_cast<const double2*>(mats + k * kHexLaneStride + p * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n_int) {
+        double nc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // row r of L = m[k][2r] (columns 0,1), m[k][2r+1] (columns 2,3)
+          double v = m[k][2 * r].x * col[0];
+          v = m[k][2 * r].y * col[1] + v;
+          v = m[k][2 * r + 1].x * col[2] + v;
+          v = m[k][2 * r + 1].y * col[3] + v;
+          nc[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[r] = nc[r];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds[g * kColGroup + q * 4 + r] = col[r];  // column-major element q*4+r
+  const unsigned long long bad = __ballot(!ok);
+  __syncthreads();
+  if (q == 0 && t < n) {
+    M4 a;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.v[k] = lds[g * kColGroup + k];
+    const bool group_ok = ((bad >> (g * 4)) & 0xfULL) == 0;
     const double det = close_determinant<ELL0>(s, f, a);
     det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
     if (!group_ok) atomicOr(flags, 1);

@@ -46,20 +46,29 @@ inline void scheme_abscissae(int scheme, double out[4]) {
   }
 }
 
+// Products whose factors are point matrices: a_i * a_j and a_i * X.
+#ifdef STORM_FAST_BUILD
+SDEV M4 m4_mul_aa(const M4& a, const M4& b) { return m4_mul_sparse<kPointMatrixZeros, kPointMatrixZeros>(a, b); }
+SDEV M4 m4_mul_ax(const M4& a, const M4& x) { return m4_mul_sparse<kPointMatrixZeros, 0u>(a, x); }
+#else
+SDEV M4 m4_mul_aa(const M4& a, const M4& b) { return m4_mul(a, b); }
+SDEV M4 m4_mul_ax(const M4& a, const M4& x) { return m4_mul(a, x); }
+#endif
+
 template <int SCHEME>
 SDEV M4 colloc_jump(const M4* a, bool& ok) {
   if constexpr (SCHEME == kColloc2) {
     return m4_scale(a[0], 0.5);
   } else if constexpr (SCHEME == kColloc4) {
-    const M4 a2a1 = m4_mul(a[1], a[0]);
+    const M4 a2a1 = m4_mul_aa(a[1], a[0]);
     const M4 k2 = m4_mul(m4_inverse(m4_eye_plus(m4_scale(a2a1, 1. / 12.)), ok), m4_add(a[1], m4_scale(a2a1, kC2_2)));
-    const M4 k1 = m4_add(a[0], m4_scale(m4_mul(a[0], k2), kC2_1));
+    const M4 k1 = m4_add(a[0], m4_scale(m4_mul_ax(a[0], k2), kC2_1));
     return m4_scale(m4_add(k1, k2), 0.25);
   } else if constexpr (SCHEME == kColloc6) {
     constexpr double d12 = -2. / 3. * kC3_1, d13 = -1. / 3. * kC3_1, d21 = 5. / 12. * kC3_1;
     constexpr double d23 = -5. / 12. * kC3_1, d31 = 1. / 3. * kC3_1, d32 = 2. / 3. * kC3_1;
-    const M4 a2a1 = m4_mul(a[1], a[0]);
-    const M4 a3a1 = m4_mul(a[2], a[0]);
+    const M4 a2a1 = m4_mul_aa(a[1], a[0]);
+    const M4 a3a1 = m4_mul_aa(a[2], a[0]);
     const M4 inv1 = m4_inverse(m4_eye_minus(m4_scale(a2a1, d12 * d21)), ok);
     const M4 o2 = m4_mul(inv1, m4_sub(a[1], m4_scale(a2a1, d21)));
     const M4 l2 = m4_mul(inv1, m4_sub(m4_scale(a[1], d23), m4_scale(a2a1, d13 * d21)));
@@ -68,11 +77,11 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 l3 = m4_sub(m4_eye_minus(m4_scale(a3a1, d13 * d31)), m4_mul(f3, l2));
     const M4 k3 = m4_mul(m4_inverse(l3, ok), o3);
     const M4 k2 = m4_sub(o2, m4_mul(l2, k3));
-    const M4 k1 = m4_mul(a[0], m4_sub(m4_eye_minus(m4_scale(k2, d12)), m4_scale(k3, d13)));
+    const M4 k1 = m4_mul_ax(a[0], m4_sub(m4_eye_minus(m4_scale(k2, d12)), m4_scale(k3, d13)));
     return m4_add(m4_add(m4_scale(k1, 5. / 36.), m4_scale(k2, 2. / 9.)), m4_scale(k3, 5. / 36.));
   } else {
     static_assert(SCHEME == kColloc8, "collocation scheme expected");
-    const M4 a2a1 = m4_mul(a[1], a[0]), a3a1 = m4_mul(a[2], a[0]), a4a1 = m4_mul(a[3], a[0]);
+    const M4 a2a1 = m4_mul_aa(a[1], a[0]), a3a1 = m4_mul_aa(a[2], a[0]), a4a1 = m4_mul_aa(a[3], a[0]);
     const M4 inv2 = m4_inverse(m4_eye_minus(m4_scale(a2a1, kD21 * kD12)), ok);
     const M4 u23 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD23), m4_scale(a2a1, kD21 * kD13)));
     const M4 u24 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD24), m4_scale(a2a1, kD21 * kD14)));
@@ -88,8 +97,8 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 k4 = m4_mul(inv4, m4_sub(m4_sub(m4_sub(a[3], m4_scale(a4a1, kD41)), m4_mul(l42, r2)), m4_mul(l43, r3)));
     const M4 k3 = m4_sub(r3, m4_mul(u34, k4));
     const M4 k2 = m4_sub(m4_sub(r2, m4_mul(u24, k4)), m4_mul(u23, k3));
-    const M4 k1 = m4_sub(m4_sub(m4_sub(a[0], m4_mul(m4_scale(a[0], kD14), k4)), m4_mul(m4_scale(a[0], kD13), k3)),
-                         m4_mul(m4_scale(a[0], kD12), k2));
+    const M4 k1 = m4_sub(m4_sub(m4_sub(a[0], m4_mul_ax(m4_scale(a[0], kD14), k4)), m4_mul_ax(m4_scale(a[0], kD13), k3)),
+                         m4_mul_ax(m4_scale(a[0], kD12), k2));
     return m4_add(m4_add(m4_add(m4_scale(k1, kW1 / 2.), m4_scale(k2, kW2 / 2.)), m4_scale(k3, kW2 / 2.)),
                   m4_scale(k4, kW1 / 2.));
   }
@@ -151,7 +160,15 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
       l.v[i] = jump.v[i] + id;
       r.v[i] = jump.v[i] - id;
     }
+#ifdef STORM_FAST_BUILD
+    // (-right^-1) * left with left = right + 2 I, i.e. -I - 2 right^-1: no product (same matrix, re-associated)
+    M4 t = m4_inverse_fast<-2>(r, ok);
+    t.v[0] = t.v[0] - 1.0; t.v[5] = t.v[5] - 1.0; t.v[10] = t.v[10] - 1.0; t.v[15] = t.v[15] - 1.0;
+    (void)l;
+    return t;
+#else
     return m4_mul(m4_neg(m4_inverse(r, ok)), l);
+#endif
   }
 }
 

@@ -89,8 +89,8 @@ def test_mode_id(host, host_models, known_answers, name):
 # ---------------------------------------------------------------------------------------------
 def each_det_path(h):
     """Forces every discriminant kernel in turn (all must give the same bits): fused, split, quad,
-    hex with 16 and with 32 lanes per frequency; restores the automatic choice afterwards."""
-    for path, lanes in ((1, 0), (2, 0), (3, 0), (4, 16), (4, 32)):
+    hex with 16 and with 32 lanes per frequency, the column-owner kernel (4 lanes); restores the automatic choice afterwards."""
+    for path, lanes in ((1, 0), (2, 0), (3, 0), (4, 16), (4, 32), (4, 4)):
         h.set_option("path", path)
         h.set_option("hex_lanes", lanes)
         yield f"path {path} lanes {lanes}"
