@@ -86,6 +86,16 @@ int storm_det_batch(storm_solver* solver, const double* freq, size_t n, double* 
  * shows as NaN in d_det_out. */
 int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
 
+/* The discriminant as mantissa * 2^exponent (mantissa in [0.5, 1), like frexp): the running product of the transfer
+ * matrices is renormalised by exact powers of two along the grid, so the result does not overflow where the reference's
+ * raw product does (det *= pivot, src/solver.rs:341,383,422,504,531; the reference detects overflow after the fact,
+ * src/dynamic_interface.rs:130-137).  An ADDITION to the raw value of storm_det_batch, which is unchanged (overflow
+ * parity): mathematically the same number; it agrees with the raw discriminant to rounding (relative ~1e-13, the closing
+ * elimination may pivot in a different order), signs included, wherever the raw one is finite.  Zero, inf and NaN are
+ * returned as such with exponent 0.  Evaluated through the staged step matrices (any batch size, chunked by
+ * "steps_bytes_max"), so it is a diagnostic path, slower than storm_det_batch for large batches. */
+int storm_det_scaled_batch(storm_solver* solver, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out);
+
 /* storm_det_batch_device for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
  * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels, same choice between
  * them and same results as storm_det_batch_device with default options, but the two scratch areas they need (the

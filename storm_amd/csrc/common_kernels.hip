@@ -47,9 +47,17 @@ SDEV double chain_step(double acc, double2 lo, double2 hi) {
   return t;
 }
 
-template <bool ELL0>
+// SCALED: the running product is renormalised by an exact power of two after every block of 16 steps (largest entry
+// brought to [1, 2)) and the exponents are summed, so the discriminant comes out as mantissa * 2^exponent and cannot
+// overflow where the reference's raw product (src/solver.rs:486-492, det *= pivot :504,531) does.  The closing
+// elimination runs on the renormalised product; with acc = 2^K acc' the discriminant is 2^(2K) times the one of acc'
+// (the two outer-boundary rows carry the factor: scale rows 2..5 by 2^-K, columns 4..7 by 2^K, the last two rows by
+// 2^-K).  Mathematically the reference's value; the pivot order may differ from the raw run's, so it agrees with the
+// raw discriminant to rounding, not bit for bit.
+template <bool ELL0, bool SCALED>
 __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
-                                                   const double* __restrict__ steps, double* __restrict__ det_out) {
+                                                   const double* __restrict__ steps, double* __restrict__ det_out,
+                                                   long long* __restrict__ exp_out) {
   __shared__ double sh[64];
   const int tid = threadIdx.x;
   const int sub = tid & 15;
@@ -59,6 +67,23 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
   const size_t fi = fi_raw < n ? fi_raw : n - 1;
   const double2* __restrict__ rows = reinterpret_cast<const double2*>(steps + fi * s.n_int * 16) + r * 2;
   double acc = (r == c) ? 1.0 : 0.0;
+  long long scale_exp = 0;
+  auto renormalise = [&]() {
+    if constexpr (SCALED) {
+      unsigned long long m = (unsigned long long)__double_as_longlong(__builtin_fabs(acc));
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const unsigned long long o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+      }
+      const int biased = (int)((m >> 52) & 0x7ff);
+      if (biased != 0 && biased != 0x7ff) {  // (zero/subnormal or non-finite: leave it)
+        const int k = biased - 1023;
+        acc = __builtin_ldexp(acc, -k);
+        scale_exp += k;
+      }
+    }
+  };
   const size_t n_int = s.n_int;
   const size_t n_blocks = n_int / kChainBlock;
   size_t i = 0;
@@ -70,17 +95,34 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
       if (b + 1 < n_blocks) chain_load(nxt, rows, (b + 1) * kChainBlock);
 #pragma unroll
       for (int u = 0; u < kChainBlock; ++u) acc = chain_step(acc, cur.lo[u], cur.hi[u]);
+      renormalise();
     }
     i = n_blocks * kChainBlock;
   }
   for (; i < n_int; ++i) acc = chain_step(acc, rows[i * 8], rows[i * 8 + 1]);
+  renormalise();
   sh[tid] = acc;  // element (r, c) at group*16 + c*4 + r: column-major, as M4 wants it
   __syncthreads();
   if (sub == 0 && fi_raw < n) {
     M4 a;
 #pragma unroll
     for (int e = 0; e < 16; ++e) a.v[e] = sh[(tid & 48) + e];
-    det_out[fi_raw] = close_determinant<ELL0>(s, freq[fi_raw], a);
+    const double det = close_determinant<ELL0>(s, freq[fi_raw], a);
+    if constexpr (SCALED) {
+      // mantissa in [0.5, 1) like frexp; zero, inf and NaN keep exponent 0
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(det);
+      const int biased = (int)((bits >> 52) & 0x7ff);
+      if (biased != 0 && biased != 0x7ff) {
+        det_out[fi_raw] = __builtin_ldexp(det, -(biased - 1022));
+        exp_out[fi_raw] = 2 * scale_exp + (biased - 1022);
+      } else {
+        det_out[fi_raw] = det;
+        exp_out[fi_raw] = det == 0.0 || det != det || biased == 0x7ff ? 0 : 2 * scale_exp;  // (subnormal: as is)
+        if (biased == 0 && det != 0.0) exp_out[fi_raw] = 2 * scale_exp;
+      }
+    } else {
+      det_out[fi_raw] = det;
+    }
   }
 }
 
@@ -88,8 +130,16 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
                         double* det_out, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 3) / 4);
-  if (ell0) chain_kernel<true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out);
-  else chain_kernel<false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out);
+  if (ell0) chain_kernel<true, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr);
+  else chain_kernel<false, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr);
+  return hipGetLastError();
+}
+hipError_t launch_chain_scaled(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
+                               double* mantissa_out, long long* exponent_out, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 3) / 4);
+  if (ell0) chain_kernel<true, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out);
+  else chain_kernel<false, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out);
   return hipGetLastError();
 }
 

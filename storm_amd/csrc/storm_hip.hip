@@ -1160,6 +1160,37 @@ int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, doub
   });
 }
 
+int storm_det_scaled_batch(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
+  return guarded([&] {
+    if (!s || (n && (!freq || !mantissa_out || !exponent_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lock(s->mu);
+    DeviceGuard g(s->device);
+    hipStream_t st = s->stream;
+    const size_t n_int = s->sys.n_int;
+    const size_t per_freq = std::max<size_t>(1, n_int) * 16 * sizeof(double);
+    size_t chunk = std::min<size_t>({n, std::max<size_t>(1, s->steps_bytes_max / per_freq), size_t(65535)});
+    s->d_freq.reserve(chunk, st); s->d_det.reserve(chunk, st);
+    s->d_bidx.reserve(chunk, st);  // (the exponents share the bracket-index buffer: 8 bytes per frequency)
+    steps_acquire(s, st);
+    s->steps_user = nullptr;
+    s->d_steps.reserve(chunk * n_int * 16 + 16, st);
+    for (size_t off = 0; off < n; off += chunk) {
+      const size_t m = std::min(chunk, n - off);
+      hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, st)), "build_steps launch");
+      hip_check((s->arith ? storm_fast::launch_chain_scaled : storm::launch_chain_scaled)(
+                    s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_det.p, reinterpret_cast<long long*>(s->d_bidx.p), st),
+                "chain launch");
+      count_launch(s, 2);
+      hip_check(hipMemcpyAsync(mantissa_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, st), "mantissa D2H");
+      hip_check(hipMemcpyAsync(exponent_out + off, s->d_bidx.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st), "exponent D2H");
+      check_flags(s);  // synchronises
+    }
+    s->stats.det_evals += n;
+  });
+}
+
 int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t n, double* d_out, void* hip_stream) {
   return guarded([&] {
     if (!s || (n && (!d_freq || !d_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");

@@ -65,7 +65,7 @@ EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "st
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
            "storm_sweep_scan_and_optimize", "storm_sweep_eigenvectors", "storm_sweep_modes", "storm_sweep_stats",
            "storm_sweep_set_option", "storm_sweep_modes_resident", "storm_sweep_coupling_matrices",
-           "storm_sweep_coupling_matrices_batch", "storm_scan_brackets", "storm_optimize_brackets", "storm_det_batch_device_noalloc", "storm_multi_create", "storm_multi_destroy",
+           "storm_sweep_coupling_matrices_batch", "storm_scan_brackets", "storm_optimize_brackets", "storm_det_batch_device_noalloc", "storm_det_scaled_batch", "storm_multi_create", "storm_multi_destroy",
            "storm_multi_devices", "storm_multi_set_option", "storm_multi_stats", "storm_multi_scan_and_optimize",
            "storm_multi_eigenvector_batch", "storm_shard_bounds"]
 
@@ -89,6 +89,7 @@ def load_library():
     L.storm_solver_destroy.restype = None
     L.storm_det_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp]
     L.storm_det_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.storm_det_scaled_batch.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp, C.POINTER(C.c_int64)]
     L.storm_det_batch_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.storm_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_uint64, C.POINTER(Bracket), C.c_size_t,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_int), _dp, C.POINTER(C.c_uint64)]
@@ -256,6 +257,14 @@ class HipSolver:
     def det_device(self, d_freq_ptr, n, d_out_ptr, stream=None):
         _check(load_library().storm_det_batch_device(self._h, C.c_void_p(d_freq_ptr), n, C.c_void_p(d_out_ptr),
                                                     C.c_void_p(stream) if stream else None))
+
+    def det_scaled(self, freqs):
+        """storm_det_scaled_batch -> (mantissa in [0.5, 1), exponent): det = mantissa * 2**exponent without overflow."""
+        f = _f64(np.atleast_1d(freqs))
+        m = np.empty(f.size)
+        e = np.zeros(f.size, dtype=np.int64)
+        _check(load_library().storm_det_scaled_batch(self._h, _p(f), f.size, _p(m), e.ctypes.data_as(C.POINTER(C.c_int64))))
+        return m, e
 
     def det_device_noalloc(self, d_freq_ptr, n, d_out_ptr, stream=None):
         _check(load_library().storm_det_batch_device_noalloc(self._h, C.c_void_p(d_freq_ptr), n, C.c_void_p(d_out_ptr),
