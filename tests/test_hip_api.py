@@ -110,6 +110,32 @@ def test_counters(oracle, oracle_models):
     assert h.stats()["eigenvectors"] == len(res)
 
 
+@pytest.mark.parametrize("scheme,ell,ulp_rel", [("colloc4", 2, 1e-8), ("magnus2", 0, None), ("colloc6", 1, 1e-12)])
+def test_device_state_machine_equals_host_state_machine(oracle, oracle_models, scheme, ell, ulp_rel):
+    """Option device_brackets: 1 (default) = sign-swap compaction + InverseQuadratic state machine as kernels, 0 = the host
+    loop of round 1.  Same brackets, end points, roots, evals and counters, and both equal the oracle's."""
+    model = oracle_models("tams")
+    o = oracle.Solver(model, ell, 0, scheme, model.field("r_coord"))
+    f = oracle.linspace(1.0, 25.0, 700)
+    ulp = 1 if ulp_rel is None else oracle.relative_to_ulp(ulp_rel)
+    ref, rdets, rinv = o.scan_and_optimize(f, ulp, threads=16)
+    out = {}
+    for dev in (0, 1):
+        h = hip_from_oracle(o)
+        h.set_option("device_brackets", dev)
+        h.stats(reset=True)
+        res, dets, inv = h.scan_and_optimize(f, ulp)
+        st = h.stats()
+        assert same_bits(dets, rdets) and inv == rinv
+        assert [b["index"] for b in res] == [b["index"] for b in ref]
+        for key in ("lo_x", "lo_f", "hi_x", "hi_f", "root"):
+            assert same_bits([b[key] for b in res], [b[key] for b in ref]), (dev, key)
+        assert [b["evals"] for b in res] == [b["evals"] for b in ref]
+        out[dev] = (st["det_evals"], st["refine_evals"], st["refine_rounds"])
+        assert st["refine_evals"] == sum(b["evals"] for b in ref) and st["refine_rounds"] == max(b["evals"] for b in ref)
+    assert out[0] == out[1]
+
+
 def test_full_size_config3_polytrope_1e5_frequencies(oracle):
     """BASELINE config 3 on one GPU: synthetic 10^4-point n=3 polytrope, ell=2, 10^5 frequencies,
     Colloc4 (CLI default) and Magnus2.  Sampled oracle comparison + size-independent properties."""
