@@ -180,10 +180,19 @@ SDEV void hex_stage_coefficients(const SystemDev& s, size_t i0, double* tile, in
   }
 }
 
+// doubles of LDS the det_hex body needs
+template <int SCHEME, int LPF>
+__host__ __device__ constexpr int hex_lds_doubles() {
+  constexpr int kHandOff = ((64 / LPF) * hex_group_stride(LPF) + 1) / 2 * 2;
+  constexpr int kTile = hex_prefetch(SCHEME, LPF) ? hex_coef_rows(SCHEME, LPF) * LPF : 2;
+  return kHandOff + 2 * kTile;
+}
+
+// The work of workgroup `block` (one wave) of det_hex; `lds`: hex_lds_doubles<SCHEME, LPF>() doubles, 16-B aligned.
 template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
-__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
-                                                     double* __restrict__ det_out, int* __restrict__ flags,
-                                                     const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
+SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, size_t n, double* __restrict__ det_out,
+                       int* __restrict__ flags, const SystemDev* __restrict__ table, const int* __restrict__ sys_index,
+                       size_t block, double* __restrict__ lds) {
   static_assert(LPF == 16 || LPF == 32 || LPF == 64, "lanes per frequency");
   constexpr int kFreqs = 64 / LPF;  // frequencies per wave
   constexpr int kGroup = hex_group_stride(LPF);
@@ -193,7 +202,6 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   // beside the LDS-DMA target hipcc waits vmcnt(0) before the first ds_read after every DMA issue, which drains the
   // prefetch at once (seen in the .s; cdna_hip_programming.md, "three .s-level traps").
   constexpr int kHandOff = (kFreqs * kGroup + 1) / 2 * 2;  // doubles, keeps the tiles 16-B aligned
-  __shared__ __attribute__((aligned(16))) double lds[kHandOff + 2 * kTile];
   double* const coef = lds + kHandOff;
   const int tid = threadIdx.x;
   const int g = tid / LPF;    // frequency within the wave
@@ -201,9 +209,9 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   const int e = tid & 15;     // element c*4+r of the product (phase B)
   const int r = e & 3;
   const int c = e >> 2;
-  const size_t t = (size_t)blockIdx.x * kFreqs + g;
+  const size_t t = block * kFreqs + g;
   // the wave's system: its own when several systems share the launch (wave-uniform, read through the scalar unit)
-  const SystemDev s = pick_system(s0, table, sys_index, (size_t)blockIdx.x * kFreqs);
+  const SystemDev s = pick_system(s0, table, sys_index, block * kFreqs);
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
@@ -270,6 +278,14 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
   }
 }
 
+template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
+                                                     double* __restrict__ det_out, int* __restrict__ flags,
+                                                     const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
+  __shared__ __attribute__((aligned(16))) double lds[hex_lds_doubles<SCHEME, LPF>()];
+  det_hex_body<SCHEME, ELL0, UNIFORM, LPF>(s0, freq, n, det_out, flags, table, sys_index, (size_t)blockIdx.x, lds);
+}
+
 // Column-owner variant ("det_col"): 4 lanes per frequency, 16 frequencies per wave.  Phase A as in det_hex (lane q builds the
 // step matrix of interval 4t+q and parks it row-major in LDS); in phase B lane c owns COLUMN c of the running product and
 // reads every step matrix whole from LDS (all four lanes of a group read the same addresses: broadcast), so the ordered
@@ -282,13 +298,12 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
-__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_col_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
-                                                                           double* __restrict__ det_out, int* __restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) double lds[16 * kColGroup];
+SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size_t n, double* __restrict__ det_out,
+                       int* __restrict__ flags, size_t block, double* __restrict__ lds) {
   const int tid = threadIdx.x;
   const int g = tid >> 2;  // frequency within the wave
   const int q = tid & 3;   // interval within the round (phase A), column of the product (phase B)
-  const size_t t = (size_t)blockIdx.x * 16 + g;
+  const size_t t = block * 16 + g;
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
@@ -344,6 +359,31 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_col_kernel(Syst
     det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
     if (!group_ok) atomicOr(flags, 1);
   }
+}
+
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_col_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+                                                                           double* __restrict__ det_out, int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) double lds[16 * kColGroup];
+  det_col_body<SCHEME, ELL0, UNIFORM>(s, freq, n, det_out, flags, (size_t)blockIdx.x, lds);
+}
+
+// Both in one launch: workgroups [0, col_blocks) run the column-owner body on the first n_col frequencies, the others the
+// 16-lane det_hex body on the rest.  The dispatcher hands out workgroups in order, so the long column-owner waves start
+// first and the short det_hex waves fill the SIMDs as those finish: the launch ends on short waves (a launch of
+// column-owner waves alone loses its 22 % instruction saving to its ragged end).
+template <int SCHEME, bool ELL0, bool UNIFORM>
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_mix_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
+                                                                           double* __restrict__ det_out, int* __restrict__ flags,
+                                                                           unsigned col_blocks) {
+  constexpr int kLds = hex_lds_doubles<SCHEME, 16>() > 16 * kColGroup ? hex_lds_doubles<SCHEME, 16>() : 16 * kColGroup;
+  __shared__ __attribute__((aligned(16))) double lds[kLds];
+  const size_t n_col = (size_t)col_blocks * 16;  // (the launcher keeps n_col <= n)
+  if (blockIdx.x < col_blocks)
+    det_col_body<SCHEME, ELL0, UNIFORM>(s, freq, n_col, det_out, flags, (size_t)blockIdx.x, lds);
+  else
+    det_hex_body<SCHEME, ELL0, UNIFORM, 16>(s, freq + n_col, n - n_col, det_out + n_col, flags, nullptr, nullptr,
+                                            (size_t)(blockIdx.x - col_blocks), lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ static size_t col_wave_slots() {
   int cus = 0, per_cu = 0;
   size_t slots = 1024;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, det_col_kernel<STORM_SCHEME, ELL0, UNIFORM>, 64, 0) == hipSuccess)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, det_mix_kernel<STORM_SCHEME, ELL0, UNIFORM>, 64, 0) == hipSuccess)
     slots = size_t(cus > 0 ? cus : 256) * size_t(per_cu > 0 ? per_cu : 4);
   if (cached) cache[dev].store(slots, std::memory_order_relaxed);
   return slots;
@@ -99,25 +99,27 @@ static size_t col_wave_slots() {
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_hex_v(const LaunchArgs& a) {
   int lpf = a.hex_lanes;
-  // Whole wave rounds of a large batch go through the column-owner kernel (4 lanes per frequency: a third of det_hex's
-  // instructions for the ordered product), the remainder through det_hex, whose waves are ~0.3 (16 lanes) or ~0.16
-  // (32 lanes) times as long.  Not for sweeps (a wave of 16 frequencies may straddle systems) and not when the caller pinned
-  // the lane count to 16 or 32.
+  // Large batches: the first ~80 % of the frequencies go to column-owner workgroups (4 lanes per frequency: a third of
+  // det_hex's instructions for the ordered product), the rest to 16-lane det_hex workgroups of the SAME launch, which
+  // start as the long column-owner waves finish and give the launch a short-wave end (det_mix_kernel).  Not for sweeps (a
+  // wave of 16 frequencies may straddle systems) and not when the caller pinned the lane count to 16 or 32; hex_lanes = 4
+  // forces the column-owner kernel alone.
   if ((lpf == 0 || lpf == 4) && a.table == nullptr && a.sys.n_int >= 4) {
-    const size_t slots = col_wave_slots<ELL0, UNIFORM>(), waves = a.n / 16;
-    // Measured (round 2, 10^5 frequencies = two wave rounds): 13 % fewer VALU instructions, 11 % fewer wave cycles, and the
-    // same launch time -- with so few, long waves the ragged end of the launch eats the gain.  So only from six rounds up.
-    const size_t bulk_waves = lpf == 4 ? (a.n + 15) / 16 : (waves >= 6 * slots ? waves / slots * slots : 0);
-    if (bulk_waves > 0) {
-      const size_t bulk_n = std::min(a.n, bulk_waves * 16);
-      det_col_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)bulk_waves, 64, 0, a.stream>>>(a.sys, a.freq, bulk_n, a.out, a.flags);
-      const hipError_t e = hipGetLastError();
-      if (e != hipSuccess || bulk_n == a.n) return e;
-      LaunchArgs tail = a;
-      tail.freq = a.freq + bulk_n; tail.out = a.out + bulk_n; tail.n = a.n - bulk_n;
-      tail.hex_lanes = 16;  // (marks "no further column-owner launch"; the choice between 16 and 32 is made below)
-      const int t = hex_cost<ELL0, UNIFORM, 32>(tail.n, tail.sys.n_int) < hex_cost<ELL0, UNIFORM, 16>(tail.n, tail.sys.n_int) ? 32 : 16;
-      return t == 32 ? launch_hex_lpf<ELL0, UNIFORM, 32>(tail) : launch_hex_lpf<ELL0, UNIFORM, 16>(tail);
+    if (lpf == 4) {
+      det_col_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)((a.n + 15) / 16), 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
+      return hipGetLastError();
+    }
+    const size_t slots = col_wave_slots<ELL0, UNIFORM>();
+    // worth it once the column-owner part alone fills the chip (one wave per slot) and leaves a det_hex part behind it
+    // worth it once the column-owner part alone fills the chip and leaves a det_hex part behind it.  (Measured at 10^5
+    // frequencies, FMA build: 80 % column-owner 19.75 ms, whole wave rounds of them (49 %) 20.67 ms, none 20.92 ms.)
+    // At 62 000 frequencies the mix LOSES 3 %, at 2*10^5 and 10^6 it gains 5 %: from 30 wave slots' worth of frequencies.
+    if (a.n >= 30 * slots) {
+      const size_t col_blocks = std::min(a.n * 4 / 5 / 16, (a.n - 1) / 16);
+      const size_t hex_blocks = (a.n - col_blocks * 16 + 3) / 4;
+      det_mix_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)(col_blocks + hex_blocks), 64, 0, a.stream>>>(
+          a.sys, a.freq, a.n, a.out, a.flags, (unsigned)col_blocks);
+      return hipGetLastError();
     }
   }
   if (lpf != 16 && lpf != 32)
