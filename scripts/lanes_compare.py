@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 98304
 scheme = sys.argv[2] if len(sys.argv) > 2 else "colloc4"
 model = host.Model.construct_polytrope(3.0, 5.0 / 3.0, 6.89684861937 / 9999.0)
 s = host.ErasedSolver(model, 2, 0, scheme, model.grid(1))
-s.set_option("profile", 1); s.set_option("hex_rounds", 0); s.set_option("path", 4)
+s.set_option("profile", 1); s.set_option("hex_rounds", 0)
 f = host.linspace(1.0, 25.0, n)
 for arith in (1, 0):
     s.set_option("arithmetic", arith)

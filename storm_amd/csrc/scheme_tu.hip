@@ -167,6 +167,19 @@ hipError_t STORM_CAT(launch_seg_fill_scheme_, STORM_SCHEME)(const LaunchArgs& a)
   return a.uniform ? launch_seg_fill_v<false, true>(a) : launch_seg_fill_v<false, false>(a);
 }
 
+// Frequencies that fill the device exactly once with 16-lane det_hex waves (wave slots x 4), and whether the launcher
+// would send this batch through det_mix; the host side cuts FMA-build batches into whole wave rounds with these.
+hipError_t STORM_CAT(launch_hexinfo_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
+  size_t* out = reinterpret_cast<size_t*>(a.out);  // [0]: frequencies per wave round, [1]: 1 if det_mix takes the batch
+  size_t slots16, slots_col;
+  if (a.ell0) { slots16 = hex_wave_slots<true, true, 16>(); slots_col = col_wave_slots<true, true>(); }
+  else if (a.uniform) { slots16 = hex_wave_slots<false, true, 16>(); slots_col = col_wave_slots<false, true>(); }
+  else { slots16 = hex_wave_slots<false, false, 16>(); slots_col = col_wave_slots<false, false>(); }
+  out[0] = slots16 * 4;
+  out[1] = (a.hex_lanes == 0 && a.table == nullptr && a.sys.n_int >= 4 && a.n >= 30 * slots_col) ? 1 : 0;
+  return hipSuccess;
+}
+
 hipError_t STORM_CAT(launch_fused_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   if (a.n == 0 ) return hipSuccess;
   if (a.ell0) return launch_fused_v<true, true>(a);

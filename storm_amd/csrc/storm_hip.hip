@@ -30,6 +30,7 @@
   hipError_t launch_build_scheme_##n(const storm::LaunchArgs&);   \
   hipError_t launch_seg_product_scheme_##n(const storm::LaunchArgs&); \
   hipError_t launch_seg_fill_scheme_##n(const storm::LaunchArgs&);    \
+  hipError_t launch_hexinfo_scheme_##n(const storm::LaunchArgs&);     \
   }
 #define STORM_DECL_ALL(ns)                                                                          \
   STORM_DECL_SCHEME(ns, 0) STORM_DECL_SCHEME(ns, 1) STORM_DECL_SCHEME(ns, 2) STORM_DECL_SCHEME(ns, 3) \
@@ -53,6 +54,7 @@ static const launch_fn g_launch_hex[2][kNumSchemes] = STORM_TABLE(hex);
 static const launch_fn g_launch_build[2][kNumSchemes] = STORM_TABLE(build);
 static const launch_fn g_launch_seg_product[2][kNumSchemes] = STORM_TABLE(seg_product);
 static const launch_fn g_launch_seg_fill[2][kNumSchemes] = STORM_TABLE(seg_fill);
+static const launch_fn g_hexinfo[2][kNumSchemes] = STORM_TABLE(hexinfo);
 
 static thread_local std::string g_error;
 
@@ -500,7 +502,7 @@ void steps_release(storm_solver* s, hipStream_t st) {
 // Segment-parallel evaluation (scheme_kernels.hpp, "Segment-parallel kernels"): how the interval axis is cut for a batch
 // of n frequencies.  n_seg == 0: not applicable.
 struct SegPlan { int n_seg = 0, seg_len = 0; };
-SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len) {
+SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len, size_t min_segments = 0) {
   SegPlan p;
   const size_t n_int = s->sys.n_int;
   if (s->arith != 1 || s->segments < 0 || n == 0 || n_int < 64) return p;  // the parity build keeps the reference's association
@@ -509,7 +511,7 @@ SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len) {
     len = (size_t(s->segments) + 15) / 16 * 16;
   } else {
     const size_t target_groups = 4096;  // 16-lane groups in flight: one wave per SIMD
-    const size_t want = std::max<size_t>(1, target_groups / n);
+    const size_t want = std::max<size_t>({size_t(1), target_groups / n, min_segments});
     len = ((n_int + want - 1) / want + 15) / 16 * 16;
     len = std::min(std::max<size_t>(len, 32), max_len);
   }
@@ -548,8 +550,32 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     count_launch(s, 2);
     steps_release(s, st);
   } else if (hex) {
+    // FMA build: all det_hex waves of a launch run equally long, so a batch of r.x wave rounds pays for the x: 12 501
+    // frequencies are 3126 waves on 3072 slots and take 1.5 rounds' time.  The whole rounds go to det_hex, the remainder
+    // (< one round) through the segment path, which has no such granularity (thousands of short groups).  This is what
+    // keeps a strong-scaled slice (10^5 / 8 frequencies per GPU) at one round.  Not in the parity build (association).
+    size_t n_hex = n;
+    SegPlan rest_plan;
+    if (s->arith == 1 && s->path == 0 && s->hex_lanes == 0 && s->segments >= 0 && n_int >= 64) {
+      size_t info[2] = {0, 0};
+      LaunchArgs q = make_args(s, d_freq, n, reinterpret_cast<double*>(info), st, flags);
+      hip_check(g_hexinfo[s->arith][s->scheme](q), "occupancy query");
+      const size_t per_round = info[0];
+      // (a remainder above a quarter round is cheaper inside det_hex: measured 20 000 frequencies 5.07 ms whole, 5.38 ms split)
+      if (!info[1] && per_round && n > per_round && n % per_round != 0 && n % per_round <= per_round / 4) {
+        const size_t rest = n % per_round;
+        rest_plan = plan_segments(s, rest, n_int, 31);
+        if (rest_plan.n_seg) n_hex = n - rest;
+      }
+    }
     ScopedTimer t(s, st, STORM_KERNEL_DET_HEX);
-    hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n, d_out, st, flags)), "det_hex launch");
+    hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n_hex, d_out, st, flags)), "det_hex launch");
+    if (n_hex < n) {
+      steps_acquire(s, st);
+      det_segments(s, rest_plan, d_freq + n_hex, n - n_hex, d_out + n_hex, st, flags);
+      steps_release(s, st);
+      count_launch(s, 2);
+    }
     t.stop();
     count_launch(s);
   } else if (quad) {
