@@ -47,8 +47,8 @@ FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "collo
 # planes with 8-byte loads, so the figure is an upper bound.  The algorithmic bytes are ~2.7 MB (planes once + 16 B per
 # frequency); the surplus is one fetch of the planes per XCD L2 and, in the FMA build, 20 B/lane of register spills.
 TRAFFIC = {("det_hex<colloc8>", 10000, 0): 2 * 10872.8e3 + 156.25e3,          # profiles/r01_pmc_det_hex_colloc8.txt
-           ("det_hex<colloc4>", 100000, 1): 2 * 10717.7e3 + 23344.9e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
-           ("det_hex<colloc4>", 100000, 0): 2 * 9240.83e3 + 781.25e3}         # profiles/r02_pmc_det_hex_colloc4_parity.txt
+           ("det_hex<colloc4>", 100000, 1): 2 * 11397.2e3 + 14602.6e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
+           ("det_hex<colloc4>", 100000, 0): 2 * 8445.33e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
 PEAK_FP64_TFLOPS = 78.6     # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz) = the dense FP64 MFMA peak
 UNFUSED_TFLOPS = 38.1       # measured chip-wide ceiling of separate v_mul_f64 / v_add_f64 (tools/fp64_microbench.hip)
 HBM_PEAK_GBS = 8000.0
@@ -227,7 +227,11 @@ def main():
              "kernel": kernel, "achieved": round(achieved, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
              "frac": round(achieved / PEAK_FP64_TFLOPS, 4), "traffic": TRAFFIC.get((kernel, len(mine), arith)),
              "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "flops_per_launch": flops_per_launch,
-             "frequencies_per_launch": len(mine), "note": NOTE[arith]}
+             "frequencies_per_launch": len(mine), "note": NOTE[arith],
+             "rocprof_row": "det_hex_kernel<colloc4,...> with 16 threads per frequency; in the FMA build, batches of >= 30 x "
+                            "wave slots (~9e4) frequencies are ONE launch of det_mix_kernel<colloc4,...> (det_hex's 16-lane "
+                            "groups and 4-lane column-owner groups side by side: DESIGN.md section 5) and a batch with a "
+                            "remainder below a quarter wave round adds fast:seg_product + fast:chain_kernel for it"}
         if arith == 0:
             r["frac_of_unfused_ceiling"] = round(achieved / UNFUSED_TFLOPS, 4)
         return r

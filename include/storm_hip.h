@@ -108,7 +108,7 @@ int storm_det_scaled_batch(storm_solver* solver, const double* freq, size_t n, d
  * the work completed; otherwise asynchronous on that stream.  All allocation-free calls on one GPU share the scratch:
  * calls that overlap on one GPU (different streams or handles) race; calls on one stream are safe. */
 #define STORM_NOALLOC_MAX_N ((size_t)1 << 24)
-#define STORM_NOALLOC_SCRATCH_BYTES (((size_t)4 << 20) + 256)
+#define STORM_NOALLOC_SCRATCH_BYTES (((size_t)16 << 20) + 256)
 int storm_det_batch_device_noalloc(storm_solver* solver, const double* d_freq, size_t n, double* d_det_out, void* hip_stream);
 
 /* Replaces ErasedSolver::scan_and_optimize (src/dynamic_interface.rs:116-160): discriminant on

@@ -217,9 +217,10 @@ using namespace storm;
 // from hipGetSymbolAddress (once per device, at the first storm_solver_create on that device) and is what the kernels
 // receive as an argument.  All calls on one GPU share it: overlapping allocation-free calls on one GPU race.
 constexpr size_t kScratchFlagBytes = 256;                    // [0, 256): flag words
-constexpr size_t kScratchPartialBytes = size_t(4) << 20;     // then: segment transfer matrices, 128 B each
+constexpr size_t kScratchPartialBytes = size_t(16) << 20;    // then: segment transfer matrices, 128 B each
 constexpr size_t kNoallocMaxN = size_t(1) << 24;             // frequencies per call (STORM_NOALLOC_MAX_N)
 static_assert(kScratchPartialBytes == STORM_NOALLOC_SCRATCH_BYTES - 256 && kNoallocMaxN == STORM_NOALLOC_MAX_N, "storm_hip.h");
+// (16 MiB: the remainder of a wave round, at most a quarter of 4 x wave slots frequencies x 32 segments x 128 B.)
 // (no __attribute__((used)): it would keep the symbol local in the device code object, where hipGetSymbolAddress cannot
 // find it; the host-side use below is what keeps the array alive and makes hipcc export it)
 static __device__ __align__(256) unsigned char scratch[kScratchFlagBytes + kScratchPartialBytes];
@@ -533,6 +534,22 @@ void det_segments(storm_solver* s, const SegPlan& plan, const double* d_freq, si
   hip_check(storm_fast::launch_chain(reduced, s->ell0, d_freq, n, s->d_partials.p, d_out, st), "chain launch");
 }
 
+// How many of n frequencies go to det_hex when the rest (less than a quarter wave round) is cheaper on the segment path
+// (FMA build only; see det_device); `rest` receives the plan of the remainder (n_seg == 0: everything goes to det_hex).
+size_t hex_whole_rounds(storm_solver* s, size_t n, SegPlan& rest) {
+  rest = SegPlan{};
+  const size_t n_int = s->sys.n_int;
+  if (!(s->arith == 1 && s->path == 0 && s->hex_lanes == 0 && s->segments >= 0 && n_int >= 64)) return n;
+  size_t info[2] = {0, 0};
+  LaunchArgs q = make_args(s, nullptr, n, reinterpret_cast<double*>(info), s->stream, nullptr);
+  hip_check(g_hexinfo[s->arith][s->scheme](q), "occupancy query");
+  const size_t per_round = info[0];
+  // (a remainder above a quarter round is cheaper inside det_hex: measured 20 000 frequencies 5.07 ms whole, 5.38 ms split)
+  if (info[1] || !per_round || n <= per_round || n % per_round == 0 || n % per_round > per_round / 4) return n;
+  rest = plan_segments(s, n % per_round, n_int, 31);
+  return rest.n_seg ? n - n % per_round : n;
+}
+
 // Core: discriminants of n device-resident frequencies into a device buffer, on stream st.
 void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, hipStream_t st, int* flags = nullptr) {
   if (n == 0) return;
@@ -554,20 +571,8 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
     // frequencies are 3126 waves on 3072 slots and take 1.5 rounds' time.  The whole rounds go to det_hex, the remainder
     // (< one round) through the segment path, which has no such granularity (thousands of short groups).  This is what
     // keeps a strong-scaled slice (10^5 / 8 frequencies per GPU) at one round.  Not in the parity build (association).
-    size_t n_hex = n;
     SegPlan rest_plan;
-    if (s->arith == 1 && s->path == 0 && s->hex_lanes == 0 && s->segments >= 0 && n_int >= 64) {
-      size_t info[2] = {0, 0};
-      LaunchArgs q = make_args(s, d_freq, n, reinterpret_cast<double*>(info), st, flags);
-      hip_check(g_hexinfo[s->arith][s->scheme](q), "occupancy query");
-      const size_t per_round = info[0];
-      // (a remainder above a quarter round is cheaper inside det_hex: measured 20 000 frequencies 5.07 ms whole, 5.38 ms split)
-      if (!info[1] && per_round && n > per_round && n % per_round != 0 && n % per_round <= per_round / 4) {
-        const size_t rest = n % per_round;
-        rest_plan = plan_segments(s, rest, n_int, 31);
-        if (rest_plan.n_seg) n_hex = n - rest;
-      }
-    }
+    const size_t n_hex = hex_whole_rounds(s, n, rest_plan);
     ScopedTimer t(s, st, STORM_KERNEL_DET_HEX);
     hip_check(g_launch_hex[s->arith][s->scheme](make_args(s, d_freq, n_hex, d_out, st, flags)), "det_hex launch");
     if (n_hex < n) {
@@ -1230,7 +1235,10 @@ int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t
     const size_t n_int = s->sys.n_int;
     // the automatic choice of storm_det_batch_device, minus the path that stages step matrices in a buffer of its own
     const SegPlan plan = n < s->hex_min_n ? plan_segments(s, n, n_int) : SegPlan{};
-    if (plan.n_seg && n * size_t(plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes)
+    SegPlan rest_plan;
+    const size_t n_hex = (plan.n_seg || n_int == 0) ? n : hex_whole_rounds(s, n, rest_plan);
+    if ((plan.n_seg && n * size_t(plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes) ||
+        (rest_plan.n_seg && (n - n_hex) * size_t(rest_plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes))
       fail(STORM_ERR_CAPACITY, "the segment transfer matrices of this call exceed the allocation-free scratch "
                                "(STORM_NOALLOC_SCRATCH_BYTES): fewer frequencies per call, or longer segments");
     if (st != s->stream) hip_check(hipStreamWaitEvent(st, s->ready, 0), "hipStreamWaitEvent");
@@ -1247,8 +1255,18 @@ int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t
       hip_check(g_launch_fused[s->arith][s->scheme](a), "det_fused launch");
       count_launch(s);
     } else {
+      a.n = n_hex;
       hip_check(g_launch_hex[s->arith][s->scheme](a), "det_hex launch");
       count_launch(s);
+      if (n_hex < n) {  // the remainder of the last wave round, as in storm_det_batch_device
+        LaunchArgs r = make_args(s, d_freq + n_hex, n - n_hex, partial, st, flags);
+        r.n_seg = rest_plan.n_seg; r.seg_len = rest_plan.seg_len;
+        hip_check(g_launch_seg_product[s->arith][s->scheme](r), "seg_product launch");
+        SystemDev reduced = s->sys;
+        reduced.n_int = size_t(rest_plan.n_seg);
+        hip_check(storm_fast::launch_chain(reduced, s->ell0, d_freq + n_hex, n - n_hex, partial, d_out + n_hex, st), "chain launch");
+        count_launch(s, 2);
+      }
     }
     s->stats.det_evals += n;
     if (!hip_stream) hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");

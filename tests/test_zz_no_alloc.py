@@ -44,6 +44,14 @@ def test_noalloc_equals_det_batch_device_two_calls_in_a_row(oracle, oracle_model
             h.det_device_noalloc(f2.data_ptr(), n2, got2.data_ptr(), stream=st.cuda_stream)
         st.synchronize()
         assert np.array_equal(bits(got1), bits(want1)) and np.array_equal(bits(got2), bits(want2))
+    # batches of a few wave rounds plus a small remainder: the FMA build sends the remainder through the segment path
+    # (storm_det_batch_device's choice); 4 x wave slots is 4096 .. 16384 frequencies per round
+    for n1 in (12501, 16500, 33000):
+        f1 = torch.from_numpy(oracle.linspace(1.0, 25.0, n1)).cuda()
+        want1, got1 = torch.zeros_like(f1), torch.full_like(f1, -1.0)
+        h.det_device(f1.data_ptr(), n1, want1.data_ptr())
+        h.det_device_noalloc(f1.data_ptr(), n1, got1.data_ptr())
+        assert np.array_equal(bits(got1), bits(want1)), (n1, arithmetic)
     if arithmetic == 0:   # and the parity build is still the oracle's bits
         f = oracle.linspace(1.0, 25.0, 200)
         d = torch.from_numpy(f).cuda()
@@ -73,12 +81,16 @@ def test_noalloc_allocates_nothing_and_rejects_oversize(oracle, oracle_models):
     assert torch.cuda.mem_get_info()[0] == free0
     assert np.array_equal(bits(out), bits(ref))
     ffi.memory_cache_limit(16 << 30, 2 << 30)
-    # a forced segment length whose transfer matrices do not fit the scratch: 300 x (1 + 3032/16 -> 192) x 128 B > 4 MiB
+    # a forced segment length whose transfer matrices do not fit the scratch: 1000 x (1 + 3032/16 -> 192) x 128 B > 16 MiB
+    big = torch.from_numpy(oracle.linspace(1.0, 20.0, 1000)).cuda()
+    big_out = torch.zeros_like(big)
     h.set_option("segments", 16)
+    h.set_option("hex_min_n", 2000)
     with pytest.raises(storm_amd.StormError) as e:
-        h.det_device_noalloc(f.data_ptr(), 300, out.data_ptr())
+        h.det_device_noalloc(big.data_ptr(), 1000, big_out.data_ptr())
     assert e.value.code == -5
     h.set_option("segments", 0)
+    h.set_option("hex_min_n", 512)
     with pytest.raises(storm_amd.StormError) as e:      # beyond STORM_NOALLOC_MAX_N (rejected before anything is read)
         h.det_device_noalloc(f.data_ptr(), (1 << 24) + 1, out.data_ptr())
     assert e.value.code == -5
