@@ -427,6 +427,31 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
             "postprocess_kernels_ms": round(k_ms, 4), "eigen_kernels_ms": round(kt["eigen"][0] / reps, 3),
             "algorithmic_GB_per_s": round(alg / (k_ms * 1e-3) / 1e9, 1) if k_ms else None, "hbm_peak_GB_per_s": HBM_PEAK_GBS,
             "radial_orders": [int(ids[0, 2]), int(ids[-1, 2])]}
+        # ---- the coupling integrals of the deformed star on M = 512 modes (the found ones, repeated):
+        # 148 un-fused flops per (left, right, grid point), FP64 VALU like the discriminant kernels
+        got = pp.modes(sd, roots, want_fields=True)
+        M = 512
+        sel = np.arange(M) % roots.size
+        c_f, c_fl = roots[sel], np.ascontiguousarray(got["fields"][sel])
+        c_ell = np.full(M, sd.ell if hasattr(sd, "ell") else 1, dtype=np.uint64)
+        x = grid
+        metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x ** 2,
+                  "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}
+        on_grid = model.eval(grid)
+        raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
+        cp = {"modes": M, "n_pts": int(grid.size), "flops_per_pair_and_point": 148,
+              "kernel": "coupling_kernel<16> (+ its two prepasses: HIP events around the three launches)"}
+        for arith in (0, 1):
+            raw.set_option("arithmetic", arith)
+            raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
+            raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
+            k_ms = raw.last_kernel_ms()
+            ach = M * M * (grid.size - 1) * 148.0 / (k_ms * 1e-3) / 1e12
+            cp["fast" if arith else "parity"] = {"bound": "compute", "pipe": "fp64-valu", "avg_launch_ms": round(k_ms, 3),
+                                                 "achieved": round(ach, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": round(ach / PEAK_FP64_TFLOPS, 4)}
+        legs["coupling_integrals"] = cp
+        del raw, c_fl, got
     del views, solvers
     pool.shutdown()
 

@@ -29,7 +29,9 @@ x = grid
 metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x ** 2,
           "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}
 raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
-for M in sizes:
+for tile, arith, M in [(t, a, m) for t in (8, 16) for a in (0, 1) for m in sizes]:
+    raw.set_option("arithmetic", arith)
+    raw.set_option("coupling_tile", tile)
     sel = np.arange(M) % freqs.size
     f, e, fl = freqs[sel], ells[sel], np.ascontiguousarray(fields[sel])
     raw.coupling_matrices(e, f, fl, 0, metric)
@@ -38,4 +40,4 @@ for M in sizes:
     wall = time.perf_counter() - t0
     ms = raw.last_kernel_ms()
     flops = M * M * (grid.size - 1) * 148.0
-    print(f"M={M:5d}  kernel {ms:9.3f} ms  {flops / ms / 1e9:8.2f} TFLOP/s (algorithmic, un-fused)   call {wall * 1e3:9.1f} ms", flush=True)
+    print(f"tile={tile:2d} arith={arith} M={M:5d}  kernel {ms:9.3f} ms  {flops / ms / 1e9:8.2f} TFLOP/s (algorithmic, un-fused)   call {wall * 1e3:9.1f} ms", flush=True)

@@ -1,0 +1,356 @@
+// coupling_kernels.hip -- the mode-coupling integrals of the deformed star (perturb_deformed, reference
+// src/perturbed.rs:110-263) on the device.  Compiled twice, like common_kernels.hip: namespace storm with
+// -ffp-contract=off (every accumulator bit-identical to the reference's sequential `+=` loop) and namespace storm_fast
+// with FMA contraction allowed (option "arithmetic" = 1 of the handle that asks; tolerance in DESIGN.md section 10).
+#include "postprocess.hpp"
+
+#include <algorithm>
+#include <type_traits>
+#include "shared_div.hpp"
+
+#ifndef STORM_NS
+#define STORM_NS storm
+#endif
+#define PDEV __device__ __forceinline__
+
+namespace STORM_NS {
+using namespace storm;
+namespace {
+// ---------------------------------------------------------------------------------------
+// Mode-coupling integrals (reference src/perturbed.rs:110-263): six M x M matrices, each element a sum over the
+// radial grid of 148 flops of products of the left and right modes' post-processing fields.
+// Lane = one (left, right) pair, wave = 8 x 8 tile of pairs; every lane walks the grid in index order with its
+// six accumulators (the reference's `+=` loop: a sequential sum), so results are bit-identical.
+// Staging: per chunk of 8 grid points the wave needs 4 fields of its 8 left modes and 5 of its 8 right modes; they
+// are copied global -> LDS by LDS-DMA (global_load_lds_dword: no VGPRs, any 4-byte alignment) one chunk ahead of
+// the arithmetic, so the serial walk never waits for memory.  The 19 mode-independent weights of a point have a
+// wave-uniform address: they are read through the constant address space (s_load, scalar cache) into SGPRs and feed
+// the FP64 instructions as scalar operands -- no LDS broadcast (that was 20 of 29 LDS reads per point), 28 fewer
+// VGPRs (121: four waves per SIMD).  FP64 VALU bound (148 flops per (pair, point); fields are read once per tile).
+// No MFMA: the contraction could be phrased as ~20 weighted GEMMs, but MFMA accumulates with fused multiply-adds
+// in its own order and would change the last bits of every element; FP64 MFMA has the same peak as the FP64
+// vector pipe on MI355X, so the only cost of staying on the VALU is the un-fused mul/add split.
+// ---------------------------------------------------------------------------------------
+constexpr int kCpChunk = 8;                                      // grid points per staged chunk
+// Geometry of a workgroup's tile of TILE x TILE (left, right) pairs: TILE = 8 (one wave) or 16 (four waves, every wave
+// an 8 x 8 block of the tile).
+template <int TILE>
+struct CpGeom {
+  static_assert(TILE == 8 || TILE == 16, "tile of 8 or 16 modes per side");
+  static constexpr int kSide = TILE / 8;                         // waves per side
+  static constexpr int kWaves = kSide * kSide;
+  static constexpr int kPlane = kCpChunk * TILE;                 // doubles: [point][mode of the tile]
+  static constexpr int kFieldTile = 9 * kPlane;                  // 4 left + 5 right planes
+  static constexpr int kDmaPerPlane = kPlane / 32;               // 256-byte DMA instructions per plane and chunk
+  static constexpr int kPtsPerDma = 32 / TILE;
+  static_assert(kDmaPerPlane % kWaves == 0, "the DMA instructions of a plane divide evenly over the waves");
+};
+
+typedef __attribute__((address_space(3))) void* cp_lds_ptr;
+typedef __attribute__((address_space(1))) const void* cp_glb_ptr;
+
+// Requests this wave's share of chunk [rc0, rc0 + 8) of the fields the workgroup needs into `tile` (points past the
+// grid are clamped to the last one).  LDS image per plane: [point][mode], so the modes of one point sit in consecutive
+// doubles (conflict-free reads, each shared by 8 lanes).  One DMA instruction moves 256 B = 32 / kCpTile points x
+// kCpTile modes; lane -> (point, mode, half of the double); wave w issues instructions w, w + kCpWaves, .. of each plane.
+// `lrow` / `rrow`: the fields row of the left / right mode this LANE stages (see coupling_body).
+// NULL_TILE: only the four planes the shortcut of coupling_body reads (left psi, p; right xi_r, rho).
+template <int TILE, bool NULL_TILE>
+PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t rc0, double* tile, int lane, int wave) {
+  constexpr int kCpTile = TILE, kCpWaves = CpGeom<TILE>::kWaves, kCpPlane = CpGeom<TILE>::kPlane;
+  constexpr int kCpDmaPerPlane = CpGeom<TILE>::kDmaPerPlane, kCpPtsPerDma = CpGeom<TILE>::kPtsPerDma;
+  const size_t np = a.n_pts;
+  const int pt_in = lane / (2 * kCpTile), word = lane & 1;
+  constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
+#pragma unroll
+  for (int pl = 0; pl < 9; ++pl) {
+    if (NULL_TILE && !(pl == 2 || pl == 3 || pl == 4 || pl == 8)) continue;
+    const double* row = a.fields + ((pl < 4 ? lrow : rrow) * kPostFields + kPlanes[pl]) * np;
+#pragma unroll
+    for (int k = 0; k < kCpDmaPerPlane / kCpWaves; ++k) {
+      const int h = wave + k * kCpWaves;  // wave-uniform
+      size_t pt = rc0 + h * kCpPtsPerDma + pt_in;
+      pt = pt < np ? pt : np - 1;
+      const char* src = reinterpret_cast<const char*>(row + pt) + word * 4;
+      __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + h * 32), 4, 0, 0);
+    }
+  }
+}
+
+// weights: uniform address, constant address space -> scalar loads
+typedef const double __attribute__((address_space(4))) * cp_const_ptr;
+
+// One workgroup = one kCpTile x kCpTile tile of (left, right) pairs; its kCpWaves waves share the staged chunks (each
+// field value of the tile is fetched once per workgroup) and every wave walks its own 8 x 8 block.
+template <int TILE>
+PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
+  constexpr int kCpTile = TILE, kCpSide = CpGeom<TILE>::kSide, kCpPlane = CpGeom<TILE>::kPlane;
+  __shared__ __attribute__((aligned(16))) double tiles[2][CpGeom<TILE>::kFieldTile];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int tl = (wave / kCpSide) * 8 + (lane >> 3), tr = (wave % kCpSide) * 8 + (lane & 7);
+  const size_t M = a.n_modes, np = a.n_pts;
+  const size_t l0 = (size_t)tile_l * kCpTile, r0 = (size_t)tile_r * kCpTile;
+  size_t lrow, rrow;
+  {
+    const int mode_in = (lane >> 1) & (kCpTile - 1);
+    size_t lmode = l0 + mode_in, rmode = r0 + mode_in;
+    lmode = lmode < M ? lmode : M - 1;
+    rmode = rmode < M ? rmode : M - 1;
+    lrow = a.rows ? (size_t)a.rows[lmode] : lmode;
+    rrow = a.rows ? (size_t)a.rows[rmode] : rmode;
+  }
+  const bool live = l0 + tl < M && r0 + tr < M;
+  const size_t lm = l0 + tl < M ? l0 + tl : M - 1, rm = r0 + tr < M ? r0 + tr : M - 1;
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lm] * a.n_ell + a.ell_index[rm]) * kCouplingConsts;
+  const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
+  const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
+  const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
+  const double k6 = ipr + 6.0 * q2;
+  const bool no_q2 = __all(q2 == 0.0 && q2_hrd == 0.0);
+  const double rfreq = a.freq[rm];
+  const cp_const_ptr wts = (cp_const_ptr)a.weights;
+  double d_squared = 0.0, d_linear = 0.0, d_zero = 0.0, r_linear = 0.0, r_zero = 0.0, l_zero = 0.0;
+  bool finite = true;
+  // this lane's nine values of point c of a tile: planes 0-3 at mode tl, 4-8 at mode tr
+  auto fetch = [&](const double* __restrict__ t, int c, double (&f)[9]) {
+#pragma unroll
+    for (int pl = 0; pl < 9; ++pl) f[pl] = t[pl * kCpPlane + c * kCpTile + (pl < 4 ? tl : tr)];
+  };
+  // Degrees more than 2 apart: all ten factors are zero.  With finite operands of moderate size every product that
+  // contains one of them is +-0, five of the six sums stay +0.0 and what is left of l_zero's term is
+  // trap r^2 ((psi_l rho'_r tea - rho psi_l xi_r adtea / r) - p_l xi_r adtea / r): adding or subtracting a zero never
+  // changes a non-zero partial sum, and an accumulator that starts at +0.0 never becomes -0.0, so the signs of the
+  // dropped zeros cannot reach the result.  "Moderate" (the `tame` flags: |v| < 2^200, so no dropped product overflows
+  // into inf * 0 = NaN) is checked per mode by coupling_tame_kernel and for the weights on the host; anything else takes
+  // the full expression below.
+  const bool all_zero = q2 == 0.0 && q2_hrd == 0.0 && q2_hld == 0.0 && q2_h == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 &&
+                        q_ht_p == 0.0 && q_ht_n == 0.0 && ipr == 0.0 && iph == 0.0;
+  // Different degrees (src/perturbed.rs:134-146): the inner products and the four toroidal factors are zero.  By the
+  // same argument a block of such pairs skips the products that contain them (about a quarter of the instructions).
+  const bool off_diag = ipr == 0.0 && iph == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 && q_ht_p == 0.0 && q_ht_n == 0.0;
+  const bool tame_block = a.tame != nullptr && a.weights_tame && __all(a.tame[lm] != 0 && a.tame[rm] != 0);
+  // The walk of this WAVE's 8 x 8 block (wave-uniform): 0 = all factors zero, 1 = different degrees, 2 = the reference's
+  // expression term by term, 3 = block outside the matrix (stages its share, no arithmetic).
+  enum { kNull = 0, kOffDiag = 1, kFull = 2, kDead = 3 };
+  const int variant = !__any(live) ? kDead : (tame_block && __all(all_zero)) ? kNull : (tame_block && __all(off_diag)) ? kOffDiag : kFull;
+  // the workgroup stages the four planes of the shortcut only if none of its waves needs more
+  const bool null_stage = __syncthreads_and(variant == kNull || variant == kDead) != 0;
+  // One walk over the grid per variant, each with the same staging and the same number of barriers: the waves of a
+  // workgroup may take different ones (the hardware barrier counts arrivals, not program addresses).
+  auto walk = [&](auto null_stage_tag, auto points_of_chunk) {
+    auto stage = [&](size_t rc0, double* tile) {
+      coupling_stage<TILE, decltype(null_stage_tag)::value>(a, lrow, rrow, rc0, tile, lane, wave);
+    };
+    stage(1, tiles[0]);
+    int buf = 0;
+    for (size_t rc0 = 1; rc0 < np; rc0 += kCpChunk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (rc0 + kCpChunk < np) stage(rc0 + kCpChunk, tiles[buf ^ 1]);
+      const int cnt = np - rc0 < (size_t)kCpChunk ? (int)(np - rc0) : kCpChunk;
+      points_of_chunk(tiles[buf], rc0, cnt);
+      buf ^= 1;
+    }
+  };
+  auto null_points = [&](const double* __restrict__ t, size_t rc0, int cnt) {
+    for (int c = 0; c < cnt; ++c) {
+      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;
+      const double lpsi = t[2 * kCpPlane + c * kCpTile + tl], lp = t[3 * kCpPlane + c * kCpTile + tl];
+      const double rxr = t[4 * kCpPlane + c * kCpTile + tr], rrho = t[8 * kCpPlane + c * kCpTile + tr];
+      const double adtea = u[CW_ADTEA];
+      double t0 = u[CW_RHO] * lpsi * rxr * adtea, t2 = lp * rxr * adtea;
+      shared_div2(t0, t2, SharedDenominator{u[CW_X], u[CW_RX], shared_div_moderate(u[CW_X])});
+      l_zero += u[CW_TR2] * (lpsi * rrho * u[CW_TEA] - t0 - t2);
+    }
+  };
+  auto points = [&](auto off_diag_tag, const double* __restrict__ t, size_t rc0, int cnt) {  // src/perturbed.rs:148-261
+    constexpr bool OFF_DIAG = decltype(off_diag_tag)::value;
+    double f[9];
+    for (int c = 0; c < cnt; ++c) {
+      fetch(t, c, f);
+      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;  // wave-uniform
+      const double lxr = f[0], lxh = f[1], lpsi = f[2], lp = f[3];
+      const double rxr = f[4], rxh = f[5], rtpv = f[6], rtnv = f[7], rrho = f[8];
+      const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+      const double eb = u[CW_EB], rho = u[CW_RHO], x = u[CW_X];
+      double val;
+      if constexpr (OFF_DIAG)
+        val = u[CW_VOL] * (rr * 2.0 * q2 * u[CW_U3] + (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+      else
+        val = u[CW_VOL] * (rr * ipr * u[CW_U1] + hh * iph * u[CW_U2] + rr * 2.0 * q2 * u[CW_U3] +
+                           (rh * q2_hrd + hr * q2_hld + hh * 2.0 * q2_h) * eb);
+      finite = finite && isfinite(val);
+      d_squared += val;
+      d_linear += u[CW_C1] * val;
+      d_zero += u[CW_C2] * val;
+      const double mrot = u[CW_MROT];
+      if constexpr (OFF_DIAG) {
+        val = u[CW_VOL2] * ((rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+        finite = finite && isfinite(val);
+        r_linear += mrot * val;
+        r_zero += mrot * (mrot * val);
+      } else {
+        const double rtp = lxr * rtpv, rtn = lxr * rtnv, htp = lxh * rtpv, htn = lxh * rtnv;
+        val = u[CW_VOL2] * (ipr * ((hr + rh) * u[CW_U4] + hh * u[CW_U2]) + (rh + hr) * q2 * u[CW_U5] + hh * k6 * 2.0 * eb);
+        const double val_t = u[CW_VOL2ROT] * (q_rt_p * rtp + q_rt_n * rtn + q_ht_n * htn + q_ht_p * htp);
+        finite = finite && isfinite(val) && isfinite(val_t);
+        r_linear += mrot * val + val_t;
+        r_zero += mrot * (mrot * val + val_t);
+      }
+      const double tea = u[CW_TEA], adtea = u[CW_ADTEA], teb = u[CW_TEB], adteb = u[CW_ADTEB];
+      const SharedDenominator den{x, u[CW_RX], shared_div_moderate(x)};  // reciprocal: coupling_recip_kernel
+      double t0, t1, t2, t3, t4, t5;
+      if (no_q2) {
+        // the four terms with a factor q2 or q2_hrd are +-0 (or NaN) for every lane of this wave and dividing them by
+        // the radius returns them unchanged: two quotients are left
+        t0 = rho * lpsi * rxr * adtea;
+        t2 = lp * rxr * adtea;
+        shared_div2(t0, t2, den);
+        t1 = rho * lpsi * q2 * rxr * adteb;
+        t3 = lp * q2 * rxr * adteb;
+        t4 = lp * q2_hrd * rxh * teb;
+        t5 = q2_hrd * rho * lpsi * rxh * teb;
+      } else {
+        double dv[6] = {rho * lpsi * rxr * adtea, rho * lpsi * q2 * rxr * adteb, lp * rxr * adtea,
+                        lp * q2 * rxr * adteb,    lp * q2_hrd * rxh * teb,       q2_hrd * rho * lpsi * rxh * teb};
+        shared_div6(dv, den);
+        t0 = dv[0]; t1 = dv[1]; t2 = dv[2]; t3 = dv[3]; t4 = dv[4]; t5 = dv[5];
+      }
+      if constexpr (OFF_DIAG) {
+        l_zero += u[CW_TR2] * (lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
+      } else {
+        const double sig = rfreq - mrot;
+        l_zero += u[CW_TR2] * ((sig * sig) * rho * (ipr * rr + iph * hh) + u[CW_C1] * sig * rho * ipr * (rh + hr + hh) +
+                               lpsi * rrho * tea - t0 + lpsi * q2 * rrho * teb - t1 - t2 - t3 - t4 + t5);
+      }
+      finite = finite && isfinite(l_zero);
+    }
+  };
+  auto no_points = [](const double*, size_t, int) {};
+  if (variant == kOffDiag) walk(std::false_type{}, [&](const double* t, size_t rc0, int cnt) { points(std::true_type{}, t, rc0, cnt); });
+  else if (variant == kFull) walk(std::false_type{}, [&](const double* t, size_t rc0, int cnt) { points(std::false_type{}, t, rc0, cnt); });
+  else if (variant == kNull && null_stage) walk(std::true_type{}, null_points);
+  else if (variant == kNull) walk(std::false_type{}, null_points);
+  else if (null_stage) walk(std::true_type{}, no_points);
+  else walk(std::false_type{}, no_points);
+  if (variant == kNull) finite = isfinite(l_zero);  // non-finite is absorbing under +=: the last value tells
+  if (live) {
+    const size_t at = lm + rm * M, mm = M * M;
+    a.out[0 * mm + at] = d_squared; a.out[1 * mm + at] = d_linear; a.out[2 * mm + at] = d_zero;
+    a.out[3 * mm + at] = r_linear; a.out[4 * mm + at] = r_zero; a.out[5 * mm + at] = l_zero;
+    if (!finite) atomicOr(a.flags, 1);
+  }
+}
+
+
+// Column CW_RX of the weights: the refined reciprocal of the radius every division of a point shares (shared_div.hpp),
+// computed once per point here instead of once per (tile, point) in the walk -- the same instructions on the same
+// input, so the same bits.
+PDEV void coupling_recip_body(const CouplingArgs& a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_pts) a.weights[i * kCouplingWeights + CW_RX] = shared_div_prepare(a.weights[i * kCouplingWeights + CW_X]).r;
+}
+
+__global__ __launch_bounds__(256) void coupling_recip_kernel(CouplingArgs a) { coupling_recip_body(a); }
+
+__global__ __launch_bounds__(256) void coupling_recip_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.y];
+  if (a.n_modes) coupling_recip_body(a);
+}
+
+// tame[k] = 1 if the frequency of mode k and every value of the seven field planes the integrals read are finite and
+// smaller than 2^200 in magnitude (exponent test on the high words).  One workgroup per mode.
+constexpr unsigned kTameLimit = unsigned(1023 + 200) << 20;
+PDEV void coupling_tame_body(const CouplingArgs& a, size_t k) {
+  __shared__ unsigned part[4];
+  const size_t row = a.rows ? (size_t)a.rows[k] : k;
+  constexpr int kPlanes[7] = {XI_R, XI_H, PSI, PRS, XI_TP, XI_TN, RHO};
+  unsigned hi = unsigned(__double2hiint(a.freq[k])) & 0x7fffffffu;
+  for (int pl = 0; pl < 7; ++pl) {
+    const double* __restrict__ v = a.fields + (row * kPostFields + kPlanes[pl]) * a.n_pts;
+    for (size_t i = threadIdx.x; i < a.n_pts; i += 256) {
+      const unsigned w = unsigned(__double2hiint(v[i])) & 0x7fffffffu;
+      hi = w > hi ? w : hi;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)hi, off);
+    hi = o > hi ? o : hi;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) hi = part[w] > hi ? part[w] : hi;
+    a.tame[k] = hi < kTameLimit ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void coupling_tame_kernel(CouplingArgs a) { coupling_tame_body(a, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void coupling_tame_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.y];
+  if (a.tame == nullptr || blockIdx.x >= a.n_modes) return;
+  coupling_tame_body(a, blockIdx.x);
+}
+
+#ifndef STORM_CP_MINWAVES16
+#define STORM_CP_MINWAVES16 4
+#endif
+template <int TILE>
+__global__ __launch_bounds__(64 * CpGeom<TILE>::kWaves, TILE == 16 ? STORM_CP_MINWAVES16 : 4) void coupling_kernel(CouplingArgs a) {
+  coupling_body<TILE>(a, blockIdx.x, blockIdx.y);
+}
+
+// blockIdx.z = problem; the grid covers the largest one, tiles past a problem's own size leave at once
+template <int TILE>
+__global__ __launch_bounds__(64 * CpGeom<TILE>::kWaves, TILE == 16 ? STORM_CP_MINWAVES16 : 4) void coupling_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.z];
+  const size_t tiles = (a.n_modes + TILE - 1) / TILE;
+  if (blockIdx.x >= tiles || blockIdx.y >= tiles) return;
+  coupling_body<TILE>(a, blockIdx.x, blockIdx.y);
+}
+}  // namespace
+
+hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
+                                 hipStream_t stream, bool with_tame, int tile) {
+  if (n_problems == 0 || max_modes == 0) return hipSuccess;
+  if (tile != 8 && tile != 16) return hipErrorInvalidValue;
+  const unsigned tiles = (unsigned)((max_modes + tile - 1) / tile);
+  if (tiles > 65535 || n_problems > 65535) return hipErrorInvalidValue;
+  if (with_tame) {
+    coupling_tame_batch_kernel<<<dim3((unsigned)max_modes, (unsigned)n_problems, 1), 256, 0, stream>>>(table);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  {
+    coupling_recip_batch_kernel<<<dim3((unsigned)((n_pts + 255) / 256), (unsigned)n_problems, 1), 256, 0, stream>>>(table);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
+  else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
+  return hipGetLastError();
+}
+
+hipError_t launch_coupling(const CouplingArgs& a, int tile) {
+  if (a.n_modes == 0) return hipSuccess;
+  if (a.n_pts < 2 || (tile != 8 && tile != 16)) return hipErrorInvalidValue;
+  const unsigned tiles = (unsigned)((a.n_modes + tile - 1) / tile);
+  if (tiles > 65535) return hipErrorInvalidValue;
+  if (a.tame) {
+    coupling_tame_kernel<<<(unsigned)a.n_modes, 256, 0, a.stream>>>(a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  coupling_recip_kernel<<<(unsigned)((a.n_pts + 255) / 256), 256, 0, a.stream>>>(a);
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (tile == 8) coupling_kernel<8><<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
+  else coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace STORM_NS

@@ -13,6 +13,7 @@ namespace storm {
 enum PostPlane : int { PP_R = 0, PP_M, PP_RHO, PP_P, PP_V, PP_U, PP_GAMMA1, PP_ASTAR, PP_C1, PP_ROT, PP_TRAP, kPostPlanes };
 
 constexpr int kPostFields = 13;  // storm_post_field of include/storm_hip.h
+enum PostField : int { Y1, Y2, Y3, Y4, XI_R, XI_H, XI_TN, XI_TP, PSI, DPSI, RHO, PRS, CHI };  // rows of a mode's field block
 
 struct PostModelDev {
   const double* tab;  // [kPostPlanes][n_pts]
@@ -100,12 +101,6 @@ struct CouplingArgs {
   int* tame = nullptr;
   int weights_tame = 0;
 };
-hipError_t launch_coupling(const CouplingArgs& args);
-// Several coupling problems in one launch: blockIdx.z picks table[z] (device array; args.stream is ignored).
-// max_modes = the largest n_modes in the table.
-// n_pts = the (common) grid size of the entries; with_tame: some entry has a `tame` array to fill first.
-hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
-                                 hipStream_t stream, bool with_tame = false);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.
@@ -113,3 +108,17 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
                               hipStream_t stream);
 
 }  // namespace storm
+
+// The coupling launchers, one set per arithmetic build (coupling_kernels.hip; storm = the reference's association,
+// storm_fast = FMA contraction allowed).  launch_coupling_batch: several coupling problems in one launch, blockIdx.z
+// picks table[z] (device array; args.stream is ignored); max_modes = the largest n_modes in the table, n_pts = the
+// (common) grid size of the entries; with_tame: some entry has a `tame` array to fill first.  tile: modes per side of a
+// workgroup's tile of pairs, 8 (one wave) or 16 (four waves sharing the staged fields).
+#define STORM_DECL_COUPLING(ns)                                                                                         \
+  namespace ns {                                                                                                        \
+  hipError_t launch_coupling(const storm::CouplingArgs& args, int tile);                                                \
+  hipError_t launch_coupling_batch(const storm::CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts, \
+                                   hipStream_t stream, bool with_tame, int tile);                                       \
+  }
+STORM_DECL_COUPLING(storm)
+STORM_DECL_COUPLING(storm_fast)

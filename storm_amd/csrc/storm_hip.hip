@@ -327,6 +327,8 @@ struct storm_postproc {
   std::vector<long long> h_ids;
   size_t bytes_max = size_t(1) << 30;  // cap of the per-batch scratch (modes are processed in chunks)
   double last_coupling_ms = 0.0;       // HIP-event duration of the last coupling kernel
+  int arith = 0;                       // coupling integrals: 0 = the reference's association, 1 = FMA build (option "arithmetic")
+  int cp_tile = 0;                     // modes per side of a workgroup's tile of pairs: 0 = automatic, 8, 16 (option "coupling_tile")
   std::mutex mu;
 };
 
@@ -1495,6 +1497,23 @@ void storm_postproc_destroy(storm_postproc* p) {
   delete p;
 }
 
+int storm_postproc_set_option(storm_postproc* p, const char* key, int64_t value) {
+  return guarded([&] {
+    if (!p || !key) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(p->mu);
+    const std::string k(key);
+    if (k == "arithmetic") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "arithmetic must be 0 (parity) or 1 (fast)");
+      p->arith = int(value);
+    } else if (k == "coupling_tile") {
+      if (value != 0 && value != 8 && value != 16) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_tile must be 0 (auto), 8 or 16");
+      p->cp_tile = int(value);
+    } else {
+      fail(STORM_ERR_INVALID_ARGUMENT, "unknown option: " + k);
+    }
+  });
+}
+
 int storm_postprocess_batch(storm_postproc* p, uint64_t ell, int64_t m, const double* freq, size_t n, const double* vec,
                             double* fields_out, storm_mode_id* ids_out, double* nodes_out, size_t node_cap) {
   return guarded([&] {
@@ -1588,8 +1607,12 @@ size_t coupling_consts(size_t n, const uint64_t* ell, int64_t m, int* ell_index,
   return ne;
 }
 
-// The kernel's shortcut for tiles whose Gaunt factors are all zero (postprocess.hip, coupling_body) needs finite
+// The kernel's shortcut for tiles whose Gaunt factors are all zero (coupling_kernels.hip, coupling_body) needs finite
 // operands of moderate size: the weights are checked here, the modes on the device.
+// Tile of the coupling kernel when the handle's "coupling_tile" is 0: 16 (four waves share every staged chunk: half the
+// L2 fetches) once the matrix has enough pairs to fill the card either way, 8 below (more, smaller workgroups).
+inline int coupling_tile_auto(size_t max_modes) { return max_modes >= 192 ? 16 : 8; }
+
 bool coupling_weights_tame(const double* w, size_t n) {
   for (size_t i = 0; i < n; ++i)
     if (!(std::fabs(w[i]) < 0x1p200)) return false;
@@ -1657,7 +1680,8 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
     if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
     hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
-    hip_check(launch_coupling(a), "coupling launch");
+    hip_check((p->arith ? storm_fast::launch_coupling : storm::launch_coupling)(a, p->cp_tile ? p->cp_tile : coupling_tile_auto(n)),
+              "coupling launch");
     hip_check(hipEventRecord(p->ev1, st), "hipEventRecord");
     // results through pinned memory (a copy to pageable memory takes the runtime's staged, host-synchronous path)
     const size_t n_out = size_t(kCouplingMatrices) * n * n;
@@ -1959,7 +1983,7 @@ struct storm_sweep {
   DevBuf<CouplingArgs> d_cp_table;
   PinnedBuf h_cp;
   PinnedBuf h_in, h_out, h_flags;
-  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0;
+  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0;
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
   storm_stats stats{};
   std::mutex mu;
@@ -2301,6 +2325,9 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "hex_lanes") {
       if (value != 0 && value != 4 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 4, 16 or 32");
       q->hex_lanes = int(value);
+    } else if (k == "coupling_tile") {
+      if (value != 0 && value != 8 && value != 16) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_tile must be 0 (auto), 8 or 16");
+      q->cp_tile = int(value);
     } else if (k == "hex_rounds") {
       if (value < 0 || value > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "hex_rounds must be 0 (one launch) .. 1024");
       q->hex_rounds = int(value);
@@ -2655,7 +2682,10 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     hip_check(hipMemcpyAsync(q->d_cp_ell.p, ell_index.data(), total * sizeof(int), hipMemcpyHostToDevice, st), "ell H2D");
     hip_check(hipMemcpyAsync(q->d_cp_table.p, table.data(), n_problems * sizeof(CouplingArgs), hipMemcpyHostToDevice, st), "table H2D");
     hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
-    hip_check(launch_coupling_batch(q->d_cp_table.p, n_problems, max_modes, np, st, with_tame), "coupling launch");
+    hip_check((q->arith ? storm_fast::launch_coupling_batch : storm::launch_coupling_batch)(q->d_cp_table.p, n_problems,
+                                                                                             max_modes, np, st, with_tame,
+                                                                                             q->cp_tile ? q->cp_tile : coupling_tile_auto(max_modes)),
+              "coupling launch");
     q->stats.launches += 1;
     // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the
     // results only after the stream has been synchronised)

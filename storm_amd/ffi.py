@@ -59,7 +59,7 @@ POST_FIELDS = ["y1", "y2", "y3", "y4", "xi_r", "xi_h", "xi_tn", "xi_tp", "psi", 
 EXPORTS = ["storm_solver_create", "storm_solver_destroy", "storm_det_batch", "storm_det_batch_device",
            "storm_scan_and_optimize", "storm_eigenvector_batch", "storm_precision_relative_to_ulp",
            "storm_solver_stats", "storm_solver_kernel_times", "storm_solver_set_option", "storm_solver_n_int", "storm_last_error",
-           "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postprocess_batch",
+           "storm_version", "storm_postproc_create", "storm_postproc_destroy", "storm_postproc_set_option", "storm_postprocess_batch",
            "storm_modes_batch", "storm_coupling_matrices", "storm_postproc_last_kernel_ms",
            "storm_memory_cache_trim", "storm_memory_cache_limit", "storm_memory_cache_stats",
            "storm_sweep_create", "storm_sweep_destroy", "storm_sweep_size", "storm_sweep_n_int", "storm_sweep_det",
@@ -107,6 +107,7 @@ def load_library():
     L.storm_postproc_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]
     L.storm_postproc_destroy.argtypes = [C.c_void_p]
     L.storm_postproc_destroy.restype = None
+    L.storm_postproc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.storm_postprocess_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, _dp, C.c_size_t, _dp, _dp,
                                           C.POINTER(ModeId), _dp, C.c_size_t]
     L.storm_modes_batch.argtypes = [C.c_void_p, C.c_void_p, _dp, C.c_size_t, _dp, _dp, _dp, C.POINTER(ModeId), _dp,
@@ -584,6 +585,10 @@ class HipPostproc:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key, value):
+        """storm_postproc_set_option ("arithmetic": 0 parity, 1 FMA build of the coupling integrals)."""
+        _check(load_library().storm_postproc_set_option(self._h, key.encode(), int(value)))
 
     def postprocess(self, ell, m, freqs, vecs, want_fields=True, node_cap=None):
         """storm_postprocess_batch on host eigenvectors [n][n_pts*4]."""

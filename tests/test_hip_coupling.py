@@ -51,6 +51,19 @@ def test_coupling_matrices_bit_exact(oracle, golden_dir, name, ells, m, rot):
     got = post.coupling_matrices(ell, freq, fields, m, metric)
     for k in storm_amd.COUPLING_MATRICES:
         assert same_bits(ref[k], got[k]), k
+    # both tile shapes of the kernel (8 x 8 pairs per one-wave workgroup, 16 x 16 per four waves sharing the staged
+    # fields) walk every pair in the same order: same bits; the FMA build ("arithmetic" = 1) stays within 1e-13 of the
+    # largest magnitude of each matrix (measured 3e-16: scripts/coupling_fast_diff.py)
+    for tile in (8, 16):
+        post.set_option("coupling_tile", tile)
+        post.set_option("arithmetic", 0)
+        again = post.coupling_matrices(ell, freq, fields, m, metric)
+        post.set_option("arithmetic", 1)
+        fast = post.coupling_matrices(ell, freq, fields, m, metric)
+        for k in storm_amd.COUPLING_MATRICES:
+            assert same_bits(ref[k], again[k]), (k, tile)
+            scale = np.max(np.abs(ref[k])) or 1.0
+            assert np.max(np.abs(fast[k] - ref[k])) <= 1e-13 * scale, (k, tile, np.max(np.abs(fast[k] - ref[k])) / scale)
     # properties: the modes of one (ell, m) are orthonormal in the mode inertia up to the O(rot^2) deformation
     # terms, and l_zero's diagonal is omega^2 to the same order
     np.testing.assert_allclose(np.diag(got["d_squared"]), 1.0, atol=0.05)
@@ -75,9 +88,9 @@ def test_coupling_with_zero_metric_is_mode_orthonormality(oracle, oracle_models)
     np.testing.assert_allclose(np.diag(got["l_zero"]), freq ** 2, rtol=1e-12)
 
 
-@pytest.mark.parametrize("n_modes", [1, 7, 8, 9, 17])
+@pytest.mark.parametrize("n_modes", [1, 7, 8, 9, 15, 16, 17])
 def test_ragged_tiles_and_host_mirror(oracle, oracle_models, n_modes):
-    # mode counts around the 8 x 8 tile of the kernel; also through the C++ host mirror (PostProcessor)
+    # mode counts around the 8 x 8 and 16 x 16 tiles of the kernel; also through the C++ host mirror (PostProcessor)
     from storm_amd import host
     model = oracle_models("zams")
     model.set_rotation_constant(0.04)
@@ -88,12 +101,16 @@ def test_ragged_tiles_and_host_mirror(oracle, oracle_models, n_modes):
     sel = np.linspace(0, freq.size - 1, n_modes).astype(int)
     ell, freq, fields = ell[sel], freq[sel], fields[sel]
     ref, _ = model.coupling_matrices(ell, freq, fields, 1, metric, threads=16)
-    got = hip_post(model).coupling_matrices(ell, freq, fields, 1, metric)
+    post = hip_post(model)
+    got = post.coupling_matrices(ell, freq, fields, 1, metric)
+    post.set_option("coupling_tile", 16)
+    got16 = post.coupling_matrices(ell, freq, fields, 1, metric)
     hm = host.Model.from_gsm_npz(os.path.join(os.path.dirname(__file__), "golden", "gsm_zams.npz"))
     hm.set_rotation_constant(0.04)
     mirror = host.PostProcessor(hm.eval(grid)).coupling_matrices(ell, freq, fields, 1, metric)
     for k in ref:
         assert same_bits(ref[k], got[k]), k
+        assert same_bits(ref[k], got16[k]), k
         assert same_bits(ref[k], mirror[k]), k
     model.set_rotation_constant(0.0)
 
@@ -196,7 +213,7 @@ def test_config5_deformed_star_pipeline(oracle, golden_dir):
 
 def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
     """Degrees more than 2 apart have all ten Gaunt factors zero and the kernel walks such 8 x 8 tiles with the three
-    terms of l_zero that carry no factor (reference src/perturbed.rs:215-236; postprocess.hip, coupling_body).  Same bits
+    terms of l_zero that carry no factor (reference src/perturbed.rs:215-236; coupling_kernels.hip, coupling_body).  Same bits
     as the full expression of the oracle: for whole tiles (16 modes of ell = 1 next to 16 of ell = 5), for modes whose
     values are too large for the shortcut's argument (it must fall back) and for a zero metric (every remaining term
     is a signed zero)."""
@@ -213,14 +230,20 @@ def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
     fields = np.ascontiguousarray(np.concatenate([p[2][:16] for p in parts]))
     post = hip_post(model)
 
-    def check(fields, metric):
+    def check(fields, metric, ell=ell, freq=freq):
         ref, _ = model.coupling_matrices(ell, freq, fields, 1, metric, threads=16)
-        got = post.coupling_matrices(ell, freq, fields, 1, metric)
-        for k in storm_amd.COUPLING_MATRICES:
-            assert same_bits(ref[k], got[k]), k
+        for tile in (16, 8):
+            post.set_option("coupling_tile", tile)
+            got = post.coupling_matrices(ell, freq, fields, 1, metric)
+            for k in storm_amd.COUPLING_MATRICES:
+                assert same_bits(ref[k], got[k]), (k, tile)
         return got
 
     got = check(fields, metric)
+    # 12 modes per degree: the 16 x 16 tiles straddle the degree blocks, so the four waves of one workgroup take
+    # different walks (all factors zero / different degrees / full expression) around the same staged chunks
+    pick = np.concatenate([np.arange(12), 16 + np.arange(12), 32 + np.arange(12)])
+    check(np.ascontiguousarray(fields[pick]), metric, ell[pick], freq[pick])
     far = np.abs(ell[:, None].astype(int) - ell[None, :].astype(int)) > 2
     assert far.sum() == 2 * 16 * 16
     for k in ("d_squared", "d_linear", "d_zero", "r_linear", "r_zero"):

@@ -148,12 +148,15 @@ static int run(int argc, char** argv) {
   if (argc < 4) { std::fprintf(stderr, "usage: storm_batch model.bin batch.txt out.txt [--group N]\n"); return 2; }
   size_t group = 16, threads = 8, shard = 0, shards = 1, pipeline = 4;
   int device = -1;
+  int64_t coupling_tile = 0, arithmetic = 0;  // options of the sweeps (include/storm_hip.h): tile of the coupling kernel, FMA build
   bool summary = false;  // --summary: one checksum per matrix instead of its n*n entries (for timing runs)
   for (int k = 4; k < argc; ++k) {
     if (!std::strcmp(argv[k], "--group") && k + 1 < argc) group = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--threads") && k + 1 < argc) threads = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--pipeline") && k + 1 < argc) pipeline = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--summary")) summary = true;
+    else if (!std::strcmp(argv[k], "--coupling-tile") && k + 1 < argc) coupling_tile = std::atoi(argv[++k]);
+    else if (!std::strcmp(argv[k], "--arithmetic") && k + 1 < argc) arithmetic = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--device") && k + 1 < argc) device = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--shard") && k + 1 < argc) {
       if (std::sscanf(argv[++k], "%zu/%zu", &shard, &shards) != 2 || shards == 0 || shard >= shards) {
@@ -260,6 +263,9 @@ static int run(int argc, char** argv) {
         SolverSweep& sweep = *sweep_ptr;
         // eigenvector staging for all modes of the group in one pass (2 MB per mode at 6199 intervals; the card has 288 GB)
         storm_sweep_set_option(sweep.handle(), "steps_bytes_max", int64_t(64) << 30);
+        if (storm_sweep_set_option(sweep.handle(), "coupling_tile", coupling_tile) != STORM_OK ||
+            storm_sweep_set_option(sweep.handle(), "arithmetic", arithmetic) != STORM_OK)
+          throw std::runtime_error(storm_last_error());
         const auto res = sweep.scan_and_optimize(grids, Precision::Relative(pv.first));
         t_scan += ms_since(t); t = Clock::now();
         std::vector<std::vector<double>> roots(rs2.size());
