@@ -173,9 +173,11 @@ int storm_postproc_create(const storm_model_desc* model, storm_postproc** out);
 void storm_postproc_destroy(storm_postproc* post);
 /* Options of a post-processing handle (no counterpart in the reference).  "arithmetic": 0 (default) = the coupling
  * integrals of storm_coupling_matrices / storm_sweep_coupling_matrices keep the reference's association and are
- * bit-identical to its sequential sums (src/perturbed.rs:148-261); 1 = the FMA build of the same kernel: every matrix
- * element within 1e-13 of the largest magnitude of its matrix (tests/test_hip_coupling.py).  The fields, norms and mode
- * identification of storm_postprocess_batch are always computed in the reference's arithmetic.
+ * bit-identical to its sequential sums (src/perturbed.rs:148-261); 1 = the FMA build (the same integrands re-associated,
+ * about twice as fast): every matrix element within 1e-13 of the largest magnitude of its matrix
+ * (tests/test_hip_coupling.py).  "coupling_tile": 0 (default, automatic), 8 or 16 modes per side of a workgroup's tile of
+ * pairs; never changes a bit of the result.  The fields, norms and mode identification of storm_postprocess_batch are
+ * always computed in the reference's arithmetic.
  * storm_sweep_coupling_matrices_batch follows the sweep's own "arithmetic" option. */
 int storm_postproc_set_option(storm_postproc* post, const char* key, int64_t value);
 

@@ -153,6 +153,64 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
       buf ^= 1;
     }
   };
+#ifdef STORM_FAST_BUILD
+  // FMA build: the same integrands re-associated so that every per-pair Gaunt factor and per-point weight enters once
+  // (src/perturbed.rs:157-252 term by term is the #else branch): with P = rho psi_l the six quotients of l_zero collapse to
+  //   -(xi_r,r / x) (P + p_l) (adtea + q2 adteb)  +  (xi_h,r teb / x) q2_hrd (P - p_l),
+  // the division by x is a multiplication by the reciprocal of the prepass, and the products xi xi of d_* / r_* are
+  // weighted by per-(pair, point) coefficients formed once.  ~70 instead of ~150 FP64 instructions per (pair, point);
+  // results differ from the reference's association by rounding only (tests/test_hip_coupling.py: 1e-13 of the largest
+  // magnitude of each matrix).  Non-finite terms are absorbing under +=, so they are looked for once, at the end.
+  const double q2x2 = 2.0 * q2, q2hx2 = 2.0 * q2_h, k6x2 = 2.0 * k6;
+  (void)no_q2;
+  auto null_points = [&](const double* __restrict__ t, size_t rc0, int cnt) {
+    for (int c = 0; c < cnt; ++c) {
+      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;
+      const double lpsi = t[2 * kCpPlane + c * kCpTile + tl], lp = t[3 * kCpPlane + c * kCpTile + tl];
+      const double rxr = t[4 * kCpPlane + c * kCpTile + tr], rrho = t[8 * kCpPlane + c * kCpTile + tr];
+      const double pl = u[CW_RHO] * lpsi + lp;
+      l_zero += u[CW_TR2] * (lpsi * rrho * u[CW_TEA] - (rxr * u[CW_RX]) * (pl * u[CW_ADTEA]));
+    }
+  };
+  auto points = [&](auto off_diag_tag, const double* __restrict__ t, size_t rc0, int cnt) {
+    constexpr bool OFF_DIAG = decltype(off_diag_tag)::value;
+    double f[9];
+    for (int c = 0; c < cnt; ++c) {
+      fetch(t, c, f);
+      const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;  // wave-uniform
+      const double lxr = f[0], lxh = f[1], lpsi = f[2], lp = f[3];
+      const double rxr = f[4], rxh = f[5], rtpv = f[6], rtnv = f[7], rrho = f[8];
+      const double rr = lxr * rxr, rh = lxr * rxh, hr = lxh * rxr, hh = lxh * rxh;
+      const double eb = u[CW_EB], rho = u[CW_RHO], mrot = u[CW_MROT];
+      const double s = rh + hr;
+      // d_squared, d_linear, d_zero
+      double c_rr = q2x2 * u[CW_U3], c_hh = q2hx2 * eb;
+      if constexpr (!OFF_DIAG) { c_rr = ipr * u[CW_U1] + c_rr; c_hh = iph * u[CW_U2] + c_hh; }
+      const double val = u[CW_VOL] * (rr * c_rr + hh * c_hh + eb * (rh * q2_hrd + hr * q2_hld));
+      d_squared += val;
+      d_linear += u[CW_C1] * val;
+      d_zero += u[CW_C2] * val;
+      // r_linear, r_zero
+      double c_s = q2 * u[CW_U5], c_h2 = k6x2 * eb;
+      if constexpr (!OFF_DIAG) { c_s = ipr * u[CW_U4] + c_s; c_h2 = ipr * u[CW_U2] + c_h2; }
+      double w = mrot * (u[CW_VOL2] * (s * c_s + hh * c_h2));
+      if constexpr (!OFF_DIAG)
+        w = u[CW_VOL2ROT] * (lxr * (q_rt_p * rtpv + q_rt_n * rtnv) + lxh * (q_ht_p * rtpv + q_ht_n * rtnv)) + w;
+      r_linear += w;
+      r_zero += mrot * w;
+      // l_zero
+      const double pp = rho * lpsi;
+      const double ca = u[CW_ADTEA] + q2 * u[CW_ADTEB], cb = u[CW_TEA] + q2 * u[CW_TEB];
+      const double rx = u[CW_RX];
+      double acc = lpsi * rrho * cb - (rxr * rx) * ((pp + lp) * ca) + (rxh * rx) * ((u[CW_TEB] * q2_hrd) * (pp - lp));
+      if constexpr (!OFF_DIAG) {
+        const double sig = rfreq - mrot;
+        acc = (sig * rho) * (sig * (ipr * rr + iph * hh) + (u[CW_C1] * ipr) * (s + hh)) + acc;
+      }
+      l_zero += u[CW_TR2] * acc;
+    }
+  };
+#else
   auto null_points = [&](const double* __restrict__ t, size_t rc0, int cnt) {
     for (int c = 0; c < cnt; ++c) {
       const cp_const_ptr u = wts + (rc0 + c) * kCouplingWeights;
@@ -227,6 +285,7 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
       finite = finite && isfinite(l_zero);
     }
   };
+#endif
   auto no_points = [](const double*, size_t, int) {};
   if (variant == kOffDiag) walk(std::false_type{}, [&](const double* t, size_t rc0, int cnt) { points(std::true_type{}, t, rc0, cnt); });
   else if (variant == kFull) walk(std::false_type{}, [&](const double* t, size_t rc0, int cnt) { points(std::false_type{}, t, rc0, cnt); });
@@ -235,6 +294,9 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   else if (null_stage) walk(std::true_type{}, no_points);
   else walk(std::false_type{}, no_points);
   if (variant == kNull) finite = isfinite(l_zero);  // non-finite is absorbing under +=: the last value tells
+#ifdef STORM_FAST_BUILD
+  else finite = isfinite(d_squared) && isfinite(r_linear) && isfinite(l_zero);
+#endif
   if (live) {
     const size_t at = lm + rm * M, mm = M * M;
     a.out[0 * mm + at] = d_squared; a.out[1 * mm + at] = d_linear; a.out[2 * mm + at] = d_zero;

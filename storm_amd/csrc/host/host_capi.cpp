@@ -314,7 +314,7 @@ int storm_host_coupling_matrices(void* p, size_t n, const uint64_t* ells, const 
     std::vector<double>* md[6] = {&pm.alpha, &pm.dalpha, &pm.ddalpha, &pm.beta, &pm.dbeta, &pm.ddbeta};
     for (int k = 0; k < 6; ++k) md[k]->assign(metric6[k], metric6[k] + np);
     const CouplingMatrices c = pp->coupling_matrices(modes, mm, pm);
-    const std::vector<double>* src[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
+    const MatrixView* src[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
     for (int k = 0; k < STORM_COUPLING_MATRICES; ++k) std::memcpy(out + size_t(k) * n * n, src[k]->data(), n * n * sizeof(double));
   });
 }

@@ -501,13 +501,10 @@ CouplingMatrices SolverSweep::coupling_matrices(const PostProcessor& post, const
   }
   storm_metric_desc md{metric.alpha.data(), metric.dalpha.data(), metric.ddalpha.data(),
                        metric.beta.data(), metric.dbeta.data(), metric.ddbeta.data()};
-  std::vector<double> out(size_t(STORM_COUPLING_MATRICES) * n * n);
-  const int rc = storm_sweep_coupling_matrices(h_, post.handle(), n, index.data(), ell.data(), freq.data(), m, &md, out.data());
-  if (rc != STORM_OK) raise_abi("storm_sweep_coupling_matrices", rc);
   CouplingMatrices c;
-  c.n = n;
-  std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
-  for (int q = 0; q < STORM_COUPLING_MATRICES; ++q) dst[q]->assign(out.begin() + size_t(q) * n * n, out.begin() + size_t(q + 1) * n * n);
+  double* out = c.allocate(n);
+  const int rc = storm_sweep_coupling_matrices(h_, post.handle(), n, index.data(), ell.data(), freq.data(), m, &md, out);
+  if (rc != STORM_OK) raise_abi("storm_sweep_coupling_matrices", rc);
   return c;
 }
 
@@ -520,7 +517,7 @@ std::vector<CouplingMatrices> SolverSweep::coupling_matrices(const std::vector<C
   std::vector<int64_t> m(P);
   std::vector<storm_metric_desc> md(P);
   std::vector<storm_postproc*> posts(P, nullptr);
-  std::vector<std::vector<double>> outs(P);
+  std::vector<CouplingMatrices> res(P);
   std::vector<double*> out_ptr(P, nullptr);
   for (size_t j = 0; j < P; ++j) {
     const CouplingProblem& pr = problems[j];
@@ -539,22 +536,11 @@ std::vector<CouplingMatrices> SolverSweep::coupling_matrices(const std::vector<C
     m[j] = pr.m;
     md[j] = storm_metric_desc{mt.alpha.data(), mt.dalpha.data(), mt.ddalpha.data(), mt.beta.data(), mt.dbeta.data(), mt.ddbeta.data()};
     posts[j] = pr.model_on_grid->handle();
-    const size_t n = pr.modes.size();
-    outs[j].resize(size_t(STORM_COUPLING_MATRICES) * n * n);
-    out_ptr[j] = outs[j].data();
+    out_ptr[j] = res[j].allocate(pr.modes.size());  // uninitialised: the library writes every element
   }
   const int rc = storm_sweep_coupling_matrices_batch(h_, P, posts.data(), off.data(), index.data(), ell.data(), freq.data(), m.data(),
                                                      md.data(), out_ptr.data());
   if (rc != STORM_OK) raise_abi("storm_sweep_coupling_matrices_batch", rc);
-  std::vector<CouplingMatrices> res(P);
-  for (size_t j = 0; j < P; ++j) {
-    CouplingMatrices& c = res[j];
-    const size_t n = problems[j].modes.size();
-    c.n = n;
-    std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
-    for (int q = 0; q < STORM_COUPLING_MATRICES; ++q)
-      dst[q]->assign(outs[j].begin() + size_t(q) * n * n, outs[j].begin() + size_t(q + 1) * n * n);
-  }
   return res;
 }
 
@@ -781,7 +767,7 @@ CouplingMatrices PostProcessor::coupling_matrices(const std::vector<ModeToPertur
                                                   const PerturbedMetric& metric) const {
   const size_t n = modes.size(), np = x_.size();
   CouplingMatrices out;
-  out.n = n;
+  double* flat = out.allocate(n);
   if (n == 0) return out;
   std::vector<uint64_t> ell(n);
   std::vector<double> freq(n), fields(n * STORM_POST_FIELDS * np);
@@ -800,12 +786,8 @@ CouplingMatrices PostProcessor::coupling_matrices(const std::vector<ModeToPertur
     if (a->size() != np) throw std::runtime_error("coupling_matrices: the metric lives on another grid");
   const storm_metric_desc md{metric.alpha.data(), metric.dalpha.data(), metric.ddalpha.data(),
                              metric.beta.data(), metric.dbeta.data(), metric.ddbeta.data()};
-  std::vector<double> flat(size_t(STORM_COUPLING_MATRICES) * n * n);
-  const int rc = storm_coupling_matrices(h_, n, ell.data(), freq.data(), fields.data(), m, &md, flat.data());
+  const int rc = storm_coupling_matrices(h_, n, ell.data(), freq.data(), fields.data(), m, &md, flat);
   if (rc != STORM_OK) raise_abi("storm_coupling_matrices", rc);
-  std::vector<double>* dst[STORM_COUPLING_MATRICES] = {&out.d_squared, &out.d_linear, &out.d_zero,
-                                                       &out.r_linear, &out.r_zero, &out.l_zero};
-  for (int c = 0; c < STORM_COUPLING_MATRICES; ++c) dst[c]->assign(flat.begin() + size_t(c) * n * n, flat.begin() + size_t(c + 1) * n * n);
   return out;
 }
 

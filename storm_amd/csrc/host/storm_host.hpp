@@ -181,10 +181,31 @@ struct ModeToPerturb {  // perturbed.rs:26-33
 // The six matrices perturb_deformed integrates (perturbed.rs:110-120), each n x n column-major like DMatrix
 // ((left, right) at left + right*n).  ModeCoupling's d, r, l are d_squared, r_linear, l_zero (perturbed.rs:313-320);
 // the generalised eigenproblem assembled from all six (perturbed.rs:265-311, linalg/qz.rs) is the caller's.
+// One n x n matrix of a CouplingMatrices block (column-major like DMatrix: element (left, right) at left + right * n).
+struct MatrixView {
+  const double* p = nullptr;
+  size_t len = 0;
+  const double* begin() const { return p; }
+  const double* end() const { return p + len; }
+  const double* data() const { return p; }
+  size_t size() const { return len; }
+  double operator[](size_t i) const { return p[i]; }
+};
+// The six matrices live in ONE block, as the device returns them (no copy per matrix: a rotation sweep moves ~3 MB per
+// rotation rate through here).
 struct CouplingMatrices {
   size_t n = 0;
-  std::vector<double> d_squared, d_linear, d_zero, r_linear, r_zero, l_zero;
-  double at(const std::vector<double>& mat, size_t left, size_t right) const { return mat[left + right * n]; }
+  MatrixView d_squared, d_linear, d_zero, r_linear, r_zero, l_zero;
+  std::unique_ptr<double[]> storage;  // [6][n * n]
+  double at(const MatrixView& mat, size_t left, size_t right) const { return mat[left + right * n]; }
+  // Allocates the block (uninitialised) and points the six views into it; returns the block for the library to fill.
+  double* allocate(size_t n_modes) {
+    n = n_modes;
+    storage.reset(new double[6 * n * n + 1]);
+    MatrixView* v[6] = {&d_squared, &d_linear, &d_zero, &r_linear, &r_zero, &l_zero};
+    for (int q = 0; q < 6; ++q) *v[q] = MatrixView{storage.get() + size_t(q) * n * n, n * n};
+    return storage.get();
+  }
 };
 
 class SolverSweep;

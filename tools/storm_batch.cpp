@@ -380,7 +380,7 @@ static int run(int argc, char** argv) {
         std::fprintf(out, "coupling %lld n %zu\n", (long long)blk.perturb[w].first, tk.n);
         if (tk.n) {
           const CouplingMatrices& c = tk.c;
-          const std::vector<double>* mats[6] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
+          const MatrixView* mats[6] = {&c.d_squared, &c.d_linear, &c.d_zero, &c.r_linear, &c.r_zero, &c.l_zero};
           for (int q = 0; q < 6; ++q) {
             std::fprintf(out, "matrix %d", q);
             if (!summary) for (double v : *mats[q]) put(out, v);
