@@ -497,13 +497,18 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_model_bin.py"), "tams", mb], check=True,
                            stdout=subprocess.DEVNULL)
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_sweep_batch.py"), bt, "64"], check=True)
-            r = subprocess.run([tool, mb, bt, os.path.join(tmp, "out.txt"), "--group", "32", "--summary", "--device",
-                                str(local_rank)], capture_output=True, text=True, timeout=300)
-            mt = re.search(r"(\d+) blocks, (\d+) scans, (\d+) modes in ([0-9.]+) ms", r.stderr)
-            if r.returncode == 0 and mt:
-                nb, ns, nm, ms = int(mt.group(1)), int(mt.group(2)), int(mt.group(3)), float(mt.group(4))
-                legs["batch_pipeline"] = {"rotation_rates": nb, "scans": ns, "modes": nm, "wall_ms": ms,
-                                          "ms_per_rotation_rate": round(ms / nb, 3), "modes_per_s": round(nm / ms * 1e3, 1)}
+            for arith, name in ((0, "parity"), (1, "fast")):
+                r = subprocess.run([tool, mb, bt, os.path.join(tmp, "out.txt"), "--group", "32", "--summary", "--device",
+                                    str(local_rank), "--arithmetic", str(arith)], capture_output=True, text=True, timeout=300)
+                mt = re.search(r"(\d+) blocks, (\d+) scans, (\d+) modes in ([0-9.]+) ms", r.stderr)
+                if r.returncode == 0 and mt:
+                    nb, ns, nm, ms = int(mt.group(1)), int(mt.group(2)), int(mt.group(3)), float(mt.group(4))
+                    rec = {"rotation_rates": nb, "scans": ns, "modes": nm, "wall_ms": ms,
+                           "ms_per_rotation_rate": round(ms / nb, 3), "modes_per_s": round(nm / ms * 1e3, 1)}
+                    if arith == 0:
+                        legs["batch_pipeline"] = rec
+                    else:
+                        legs.setdefault("batch_pipeline", {})["fast"] = rec
     return legs
 
 
