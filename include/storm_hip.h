@@ -316,9 +316,14 @@ void storm_shard_bounds(size_t n, size_t n_parts, size_t k, size_t* lo, size_t* 
 /* ---- Memory cache (no counterpart in the reference) ----
  * Handles draw their device buffers, pinned staging buffers and streams from a process-wide cache and return them to
  * it on destroy, because hipFree / hipStreamDestroy synchronise the whole device and would serialise the concurrent
- * small scans of a rotation sweep (one handle per (ell, m, rotation rate) system).  Defaults: up to 16 GiB of device
- * memory and 2 GiB of pinned host memory stay cached.  A caller that used storm_det_batch_device with its own stream
- * must synchronise that stream before destroying the handle. */
+ * small scans of a rotation sweep (one handle per (ell, m, rotation rate) system), and because fresh memory can cost
+ * ~30 ms per GB when the driver has to clear it first.  Default: every block is carved out of
+ * slabs the library allocates as the need grows (4 GiB doubling to 32 GiB for blocks of 64 MiB and more, smaller ones for
+ * smaller blocks; pinned host memory likewise) and keeps until storm_memory_cache_trim, below three quarters of the
+ * device's memory in all.  storm_memory_cache_limit switches to separately allocated blocks of which the given number
+ * of bytes may stay cached.  storm_memory_cache_stats counts idle bytes (free slab space included).
+ * A caller that used storm_det_batch_device with its own stream must synchronise that stream before destroying the
+ * handle. */
 int storm_memory_cache_trim(void);                                            /* give everything cached back to HIP */
 int storm_memory_cache_limit(size_t device_bytes, size_t pinned_host_bytes);  /* what may stay cached from now on */
 void storm_memory_cache_stats(size_t* device_bytes, size_t* pinned_host_bytes); /* currently cached (either may be NULL) */

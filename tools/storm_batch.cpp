@@ -156,6 +156,9 @@ static int run(int argc, char** argv) {
     else if (!std::strcmp(argv[k], "--pipeline") && k + 1 < argc) pipeline = std::strtoul(argv[++k], nullptr, 10);
     else if (!std::strcmp(argv[k], "--summary")) summary = true;
     else if (!std::strcmp(argv[k], "--coupling-tile") && k + 1 < argc) coupling_tile = std::atoi(argv[++k]);
+    else if (!std::strcmp(argv[k], "--cache-gb") && k + 1 < argc) {  // fixed cache limit instead of the library's slab policy (for comparison)
+      if (storm_memory_cache_limit(size_t(std::atoi(argv[++k])) << 30, size_t(8) << 30) != STORM_OK) return 2;
+    }
     else if (!std::strcmp(argv[k], "--arithmetic") && k + 1 < argc) arithmetic = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--device") && k + 1 < argc) device = std::atoi(argv[++k]);
     else if (!std::strcmp(argv[k], "--shard") && k + 1 < argc) {
@@ -187,9 +190,9 @@ static int run(int argc, char** argv) {
   FILE* final_out = std::fopen(argv[3], "w");
   if (!final_out) { std::perror(argv[3]); return 2; }
 
-  // Every group in flight stages ~2.7 MB per mode (step matrices, factors, eigenvectors, fields): let the library keep
-  // those blocks between groups instead of returning them to HIP (hipFree synchronises the device).
-  storm_memory_cache_limit(size_t(160) << 30, size_t(8) << 30);
+  // Every group in flight stages ~2.7 MB per mode (step matrices, factors, eigenvectors, fields).  The library's default
+  // memory policy (slabs carved into blocks, kept while its footprint is below 3/4 of the device) recycles all of it
+  // without calling hipMalloc / hipFree mid-run; --cache-gb replaces it by a fixed cache of separately allocated blocks.
   const auto t_all = Clock::now();
   struct Totals { double t_scan = 0, t_modes = 0, t_deform = 0, t_couple = 0, t_write = 0; size_t n_scans = 0, n_modes = 0; } tot;
   std::mutex tot_mu;
