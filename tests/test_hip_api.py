@@ -272,3 +272,41 @@ def test_handle_per_scan_from_many_threads_and_memory_cache(oracle, golden_dir):
     run(jobs[1])
     assert ffi.memory_cache_stats() == (0, 0)
     ffi.memory_cache_limit(16 << 30, 2 << 30)
+
+
+def test_buffers_of_every_size_band_are_recycled_through_the_slabs(oracle, oracle_models):
+    # The library carves its device and pinned blocks out of slabs (three size bands: below 1 MiB, 1-64 MiB, above).
+    # Three handles take turns with batches whose buffers grow and shrink through all bands (800 B to 240 MB: 3 x 10^7
+    # frequencies would be too slow to check, so the large band comes from eigenvector staging of 40 modes at 2 MB each);
+    # every result must stay bit-identical to the oracle's whatever block a buffer landed in, idle bytes must show in the
+    # statistics and a trim must give everything back.
+    from storm_amd import ffi
+    model = oracle_models("tams")
+    grid = model.field("r_coord")
+    solvers = []
+    for ell, scheme in ((1, "colloc4"), (2, "magnus2"), (3, "colloc2")):
+        o = oracle.Solver(model, ell, 0, scheme, grid)
+        solvers.append((o, hip_from_oracle(o)))
+    ffi.memory_cache_trim()
+    for n in (100, 40000, 700, 200000, 5000, 100):
+        for o, h in solvers:
+            f = oracle.linspace(1.0 + 0.01 * o.ell, 24.0, n)
+            got = h.det(f)
+            pick = np.unique(np.linspace(0, n - 1, 97).astype(int))
+            assert same_bits(got[pick], o.det(f[pick], threads=16)), (o.scheme, n)
+    roots = oracle.linspace(2.0, 20.0, 40)
+    for o, h in solvers[:2]:
+        det, vec = h.eigenvector(roots)
+        rdet, rvec = o.eigenvector(roots, threads=16)
+        assert same_bits(det, rdet) and same_bits(vec, rvec)
+    for _, h in solvers:
+        h.close()
+    dev, pinned = ffi.memory_cache_stats()
+    assert dev >= (64 << 20) and pinned > 0        # the slabs stay, with everything in them idle
+    ffi.memory_cache_trim()
+    assert ffi.memory_cache_stats() == (0, 0)
+    o, _ = solvers[0]
+    h = hip_from_oracle(o)                          # and the library carries on from nothing
+    f = oracle.linspace(1.0, 24.0, 300)
+    assert same_bits(h.det(f), o.det(f, threads=16))
+    h.close()
