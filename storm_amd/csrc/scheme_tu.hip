@@ -96,6 +96,19 @@ static size_t col_wave_slots() {
   if (cached) cache[dev].store(slots, std::memory_order_relaxed);
   return slots;
 }
+// Does det_mix take this batch?  It pays where the column-owner body keeps det_hex's occupancy: measured at 10^5
+// frequencies on tams (scripts/time_scheme.py, det_mix vs det_hex alone, parity | FMA build, ms): Colloc2 10.6 vs 11.4 |
+// 5.9 vs 6.9, Colloc4 23.5 vs 24.3 | 12.6 vs 13.3, Magnus2/4/6 2-3 % | 5-7 % faster, Magnus8 72.9 vs 78.1 | 48.3 vs 52.8;
+// NOT for Colloc6 (58.1 vs 43.8 | 33.8 vs 25.1: the mixed kernel needs more than 256 registers and loses the second
+// wave per SIMD) and Colloc8 (119.9 vs 108.2 | 64.3 vs 64.4).
+template <bool ELL0, bool UNIFORM>
+static bool mix_takes(const LaunchArgs& a) {
+  if (STORM_SCHEME == kColloc6 || STORM_SCHEME == kColloc8) return false;
+  // worth it once the column-owner part alone fills the chip and leaves a det_hex part behind it.  (Measured at 10^5
+  // frequencies, FMA build, Colloc4: 80 % column-owner 19.75 ms, whole wave rounds of them (49 %) 20.67 ms, none 20.92 ms.)
+  // At 62 000 frequencies the mix LOSES 3 %, at 2*10^5 and 10^6 it gains 5 %: from 30 wave slots' worth of frequencies.
+  return a.hex_lanes == 0 && a.table == nullptr && a.sys.n_int >= 4 && a.n >= 30 * col_wave_slots<ELL0, UNIFORM>();
+}
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_hex_v(const LaunchArgs& a) {
   int lpf = a.hex_lanes;
@@ -109,12 +122,7 @@ static hipError_t launch_hex_v(const LaunchArgs& a) {
       det_col_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)((a.n + 15) / 16), 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
       return hipGetLastError();
     }
-    const size_t slots = col_wave_slots<ELL0, UNIFORM>();
-    // worth it once the column-owner part alone fills the chip (one wave per slot) and leaves a det_hex part behind it
-    // worth it once the column-owner part alone fills the chip and leaves a det_hex part behind it.  (Measured at 10^5
-    // frequencies, FMA build: 80 % column-owner 19.75 ms, whole wave rounds of them (49 %) 20.67 ms, none 20.92 ms.)
-    // At 62 000 frequencies the mix LOSES 3 %, at 2*10^5 and 10^6 it gains 5 %: from 30 wave slots' worth of frequencies.
-    if (a.n >= 30 * slots) {
+    if (mix_takes<ELL0, UNIFORM>(a)) {
       const size_t col_blocks = std::min(a.n * 4 / 5 / 16, (a.n - 1) / 16);
       const size_t hex_blocks = (a.n - col_blocks * 16 + 3) / 4;
       det_mix_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)(col_blocks + hex_blocks), 64, 0, a.stream>>>(
@@ -171,12 +179,13 @@ hipError_t STORM_CAT(launch_seg_fill_scheme_, STORM_SCHEME)(const LaunchArgs& a)
 // would send this batch through det_mix; the host side cuts FMA-build batches into whole wave rounds with these.
 hipError_t STORM_CAT(launch_hexinfo_scheme_, STORM_SCHEME)(const LaunchArgs& a) {
   size_t* out = reinterpret_cast<size_t*>(a.out);  // [0]: frequencies per wave round, [1]: 1 if det_mix takes the batch
-  size_t slots16, slots_col;
-  if (a.ell0) { slots16 = hex_wave_slots<true, true, 16>(); slots_col = col_wave_slots<true, true>(); }
-  else if (a.uniform) { slots16 = hex_wave_slots<false, true, 16>(); slots_col = col_wave_slots<false, true>(); }
-  else { slots16 = hex_wave_slots<false, false, 16>(); slots_col = col_wave_slots<false, false>(); }
+  size_t slots16;
+  bool mix;
+  if (a.ell0) { slots16 = hex_wave_slots<true, true, 16>(); mix = mix_takes<true, true>(a); }
+  else if (a.uniform) { slots16 = hex_wave_slots<false, true, 16>(); mix = mix_takes<false, true>(a); }
+  else { slots16 = hex_wave_slots<false, false, 16>(); mix = mix_takes<false, false>(a); }
   out[0] = slots16 * 4;
-  out[1] = (a.hex_lanes == 0 && a.table == nullptr && a.sys.n_int >= 4 && a.n >= 30 * slots_col) ? 1 : 0;
+  out[1] = mix ? 1 : 0;
   return hipSuccess;
 }
 
