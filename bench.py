@@ -170,14 +170,20 @@ def main():
     freqs = host.linspace(1.0, 25.0, N_FREQ)
     lo_idx, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
 
+    vec_buf = np.empty(64 * (n_int + 1) * 4)  # the caller's eigenvector block, reused from scan to scan
+
     def eigenvectors(brackets):
+        nonlocal vec_buf
         if brackets:
-            h.eigenvector(np.array([b["root"] for b in brackets]))
+            need = len(brackets) * (n_int + 1) * 4
+            if vec_buf.size < need:
+                vec_buf = np.empty(need)
+            h.eigenvector(np.array([b["root"] for b in brackets]), out=vec_buf)
 
     def one_scan():
         """StormState::scan on this rank's share; returns the global bracket list."""
         if world == 1:
-            res, _, _ = h.scan_and_optimize(freqs, ulp, cap=8192)
+            res, _, _ = h.scan_and_optimize(freqs, ulp, cap=8192, want_dets=False)  # (the reference returns brackets only)
             eigenvectors(res)
             return res
         res, _, _ = D.strong_scan_and_optimize(h, freqs, ulp, device=coll_device, after_refine=eigenvectors)

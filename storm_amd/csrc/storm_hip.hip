@@ -2017,8 +2017,16 @@ void on_every_device(size_t n, Job&& job) {
   std::vector<int> rc(n, STORM_OK);
   std::vector<std::string> msg(n);
   auto run = [&](size_t k) {
-    rc[k] = job(k);
-    if (rc[k] != STORM_OK) msg[k] = g_error;  // (thread-local: read on the thread that failed)
+    try {
+      rc[k] = job(k);
+      if (rc[k] != STORM_OK) msg[k] = g_error;  // (thread-local: read on the thread that failed)
+    } catch (const std::bad_alloc&) {  // (sizing a part: an exception must not leave a worker thread)
+      rc[k] = STORM_ERR_HIP;
+      msg[k] = "out of host memory";
+    } catch (const std::exception& e) {
+      rc[k] = STORM_ERR_INVALID_ARGUMENT;
+      msg[k] = e.what();
+    }
   };
   std::vector<std::thread> pool;
   for (size_t k = 1; k < n; ++k) pool.emplace_back(run, k);

@@ -271,16 +271,18 @@ class HipSolver:
         _check(load_library().storm_det_batch_device_noalloc(self._h, C.c_void_p(d_freq_ptr), n, C.c_void_p(d_out_ptr),
                                                             C.c_void_p(stream) if stream else None))
 
-    def scan_and_optimize(self, freqs, ulp, cap=None):
+    def scan_and_optimize(self, freqs, ulp, cap=None, want_dets=True):
+        """storm_scan_and_optimize -> (brackets, dets, invalid); want_dets=False: the reference's return value only (the
+        discriminants of the grid stay on the device: dets is None)."""
         f = _f64(freqs)
         cap = max(1, f.size) if cap is None else cap
         out = (Bracket * max(cap, 1))()
         idx = (C.c_uint64 * max(cap, 1))()
-        dets = np.empty(f.size)
+        dets = np.empty(f.size) if want_dets else None
         n_out = C.c_size_t(0)
         inv = C.c_int(0)
         _check(load_library().storm_scan_and_optimize(self._h, _p(f), f.size, ulp, out, cap, C.byref(n_out),
-                                                      C.byref(inv), _p(dets), idx))
+                                                      C.byref(inv), _p(dets) if want_dets else None, idx))
         res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
                     index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
         return res, dets, bool(inv.value)
@@ -314,10 +316,18 @@ class HipSolver:
             out.append(d)
         return out
 
-    def eigenvector(self, freqs):
+    def eigenvector(self, freqs, out=None):
+        """storm_eigenvector_batch -> (dets, vec[n][(n_int + 1) * 4]); out: a float64 array of at least that many elements
+        to write the eigenvectors into (a caller that scans repeatedly keeps one instead of touching fresh pages)."""
         f = _f64(np.atleast_1d(freqs))
         dets = np.empty(f.size)
-        vec = np.empty((f.size, (self.n_int + 1) * 4))
+        length = (self.n_int + 1) * 4
+        if out is None:
+            vec = np.empty((f.size, length))
+        else:
+            if out.dtype != np.float64 or not out.flags.c_contiguous or out.size < f.size * length:
+                raise ValueError("out must be a C-contiguous float64 array of at least n * (n_int + 1) * 4 elements")
+            vec = out.reshape(-1)[:f.size * length].reshape(f.size, length)
         _check(load_library().storm_eigenvector_batch(self._h, _p(f), f.size, _p(dets), _p(vec)))
         return dets, vec
 
