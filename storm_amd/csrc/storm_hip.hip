@@ -2222,6 +2222,15 @@ struct storm_sweep {
   DevBuf<CouplingArgs> d_cp_table;
   PinnedBuf h_cp;
   PinnedBuf h_in, h_out, h_flags;
+  // segment-parallel eigenvectors (FMA build): transfer matrices, boundary vectors, growth guard, the systems with
+  // n_int = number of segments for the boundary elimination
+  DevBuf<double> d_partials, d_seg_nodes;
+  DevBuf<unsigned long long> d_growth;
+  DevBuf<SystemDev> d_table_red;
+  std::vector<SystemDev> h_table_red;
+  PinnedBuf h_growth;
+  int segments = 0;           // option "segments": -1 = never, 0 = automatic (FMA build only)
+  double seg_growth_max = 0x1p24;
   int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0;
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
   storm_stats stats{};
@@ -2352,11 +2361,82 @@ size_t set_eigen_reserve(storm_sweep* q, size_t n) {
   if (chunk > n) chunk = n;
   if (chunk > 65535) chunk = 65535;  // grid.y of build_steps
   q->d_freq.reserve(chunk, q->stream); q->d_det.reserve(chunk, q->stream); q->d_sys.reserve(chunk, q->stream);
-  q->d_steps.reserve(chunk * n_int * 16 + 16, q->stream);
-  q->d_upper.reserve((chunk + 64) * ustride, q->stream);  // lane-per-mode kernels pad the mode count to 64
   q->d_vec.reserve((chunk + 64) * len, q->stream);
   q->d_swaps.reserve(chunk * 2, q->stream);
+  // (step matrices and factors of the sequential elimination, 2 MB per mode: reserved where that path is taken)
   return chunk;
+}
+
+bool set_uses_segments(const storm_sweep* q) { return q->arith == 1 && q->segments >= 0 && q->n_int >= 64; }
+
+// Segment-parallel eigenvectors of one chunk (FMA build; the single-handle version is eigen_segments): transfer matrices
+// of every (mode, segment) pair, the reference's elimination + back-substitution on the system of the segment boundaries
+// (every mode with its own system's boundary rows: the table with n_int = n_seg), then the fill of every segment.  No
+// step matrices are staged (2 MB per mode in the sequential path; here 128 B per (mode, segment)).  Returns false if a
+// transfer matrix grew past the guard: the caller then takes the sequential path for the chunk.
+bool set_eigen_segments(storm_sweep* q, const int* pos, size_t m) {
+  const size_t n_int = q->n_int, len = (n_int + 1) * 4, S = q->n_sys;
+  const size_t want = std::max<size_t>(1, 4096 / m);
+  size_t seg_len = ((n_int + want - 1) / want + 15) / 16 * 16;
+  seg_len = std::min<size_t>(std::max<size_t>(seg_len, 32), 256);
+  const size_t n_seg = (1 + (n_int - 1 + seg_len - 1) / seg_len + 3) / 4 * 4;  // the first interval is a segment of its own
+  if (m * n_seg / 4 >= (size_t(1) << 31)) return false;
+  const size_t ustride = n_seg * 22 + 6, nstride = (n_seg + 1) * 4;
+  q->d_partials.reserve(m * n_seg * 16, q->stream);
+  q->d_seg_nodes.reserve((m + 64) * nstride, q->stream);
+  q->d_growth.reserve(m, q->stream);
+  q->d_upper.reserve((m + 64) * ustride, q->stream);
+  q->d_table_red.reserve(S, q->stream);
+  q->h_table_red = q->h_table;
+  for (SystemDev& t : q->h_table_red) t.n_int = n_seg;
+  hip_check(hipMemcpyAsync(q->d_table_red.p, q->h_table_red.data(), S * sizeof(SystemDev), hipMemcpyHostToDevice, q->stream), "table H2D");
+  hip_check(hipMemsetAsync(q->d_growth.p, 0, m * sizeof(unsigned long long), q->stream), "growth memset");
+  size_t first = 0;
+  std::vector<std::pair<size_t, size_t>> cls(kSetClasses, {0, 0});
+  for (int c = 0; c < kSetClasses; ++c) {
+    size_t last = first;
+    while (last < m && size_t(pos[last]) < q->cls_begin[c + 1]) ++last;
+    cls[c] = {first, last - first};
+    first = last;
+  }
+  for (int c = 0; c < kSetClasses; ++c) {
+    const size_t at = cls[c].first, n = cls[c].second;
+    if (!n) continue;
+    LaunchArgs a = set_args(q, c, at, n, q->d_partials.p + at * n_seg * 16);
+    a.n_seg = int(n_seg); a.seg_len = int(seg_len); a.growth = q->d_growth.p + at;
+    hip_check(g_launch_seg_product[q->arith][q->scheme](a), "seg_product launch");
+    q->stats.launches += 1;
+  }
+  if (storm::eigen_uses_lanes(m, q->eigen_layout)) {
+    hip_check(storm_fast::launch_eigen(q->h_table_red[0], 2, q->d_freq.p, m, q->d_partials.p, q->d_upper.p, q->d_swaps.p, q->d_det.p,
+                                       q->d_seg_nodes.p, q->stream, q->d_table_red.p, q->d_sys.p, 2), "eigen launch");
+    q->stats.launches += 2;
+  } else {
+    for (int c = 0; c < kSetClasses; ++c) {
+      const size_t at = cls[c].first, n = cls[c].second;
+      if (!n) continue;
+      hip_check(storm_fast::launch_eigen(q->h_table_red[q->cls_begin[c]], set_class_ell0(c) ? 1 : 0, q->d_freq.p + at, n,
+                                         q->d_partials.p + at * n_seg * 16, q->d_upper.p + at * ustride, q->d_swaps.p + at * 2,
+                                         q->d_det.p + at, q->d_seg_nodes.p + at * nstride, q->stream, q->d_table_red.p,
+                                         q->d_sys.p + at, 1), "eigen launch");
+      q->stats.launches += 2;
+    }
+  }
+  for (int c = 0; c < kSetClasses; ++c) {
+    const size_t at = cls[c].first, n = cls[c].second;
+    if (!n) continue;
+    LaunchArgs a = set_args(q, c, at, n, nullptr);
+    a.n_seg = int(n_seg); a.seg_len = int(seg_len);
+    a.nodes = q->d_seg_nodes.p + at * nstride; a.vec = q->d_vec.p + at * len;
+    hip_check(g_launch_seg_fill[q->arith][q->scheme](a), "seg_fill launch");
+    q->stats.launches += 1;
+  }
+  q->h_growth.reserve(m);
+  hip_check(hipMemcpyAsync(q->h_growth.p, q->d_growth.p, m * sizeof(unsigned long long), hipMemcpyDeviceToHost, q->stream), "growth D2H");
+  sync_stream(q->stream, q->sync_marker);
+  for (size_t k = 0; k < m; ++k)
+    if (!(q->h_growth.p[k] <= q->seg_growth_max)) return false;  // (the bit patterns of |T|, read as doubles)
+  return true;
 }
 
 // Modes of one chunk, sorted by internal system position: step matrices + elimination + back-substitution, one
@@ -2369,6 +2449,12 @@ void set_eigen_chunk(storm_sweep* q, const double* freq, const int* pos, size_t 
   hip_check(hipMemcpyAsync(q->d_freq.p, q->h_in.p, m * sizeof(double), hipMemcpyHostToDevice, q->stream), "freq H2D");
   hip_check(hipMemcpyAsync(q->d_sys.p, hs, m * sizeof(int), hipMemcpyHostToDevice, q->stream), "system index H2D");
   const size_t n_int = q->n_int, len = (n_int + 1) * 4, ustride = n_int * 22 + 6;
+  if (set_uses_segments(q)) {
+    if (set_eigen_segments(q, pos, m)) { q->stats.eigenvectors += m; return; }
+    q->stats.segment_fallbacks += m;  // a transfer matrix too large to propagate through: the whole chunk sequentially
+  }
+  q->d_steps.reserve(m * n_int * 16 + 16, q->stream);
+  q->d_upper.reserve((m + 64) * ustride, q->stream);  // lane-per-mode kernels pad the mode count to 64
   auto eigen = q->arith ? storm_fast::launch_eigen : storm::launch_eigen;
   // with the lane-per-mode kernels the whole chunk is eliminated in one launch whatever the systems' classes
   const bool lanes = storm::eigen_uses_lanes(m, q->eigen_layout);
@@ -2546,6 +2632,7 @@ void storm_sweep_destroy(storm_sweep* q) {
   q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
   q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release();
   q->d_cp_table.release(); q->h_cp.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
+  q->d_partials.release(); q->d_seg_nodes.release(); q->d_growth.release(); q->d_table_red.release(); q->h_growth.release();
   (void)hipSetDevice(prev);
   delete q;
 }
@@ -2567,6 +2654,12 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "coupling_tile") {
       if (value != 0 && value != 8 && value != 16) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_tile must be 0 (auto), 8 or 16");
       q->cp_tile = int(value);
+    } else if (k == "segments") {
+      if (value != 0 && value != -1) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be 0 (automatic, FMA build only) or -1 (never)");
+      q->segments = int(value);
+    } else if (k == "seg_growth_log2") {
+      if (value < 0 || value > 1000) fail(STORM_ERR_INVALID_ARGUMENT, "seg_growth_log2 must be 0 .. 1000");
+      q->seg_growth_max = std::ldexp(1.0, int(value));
     } else if (k == "hex_rounds") {
       if (value < 0 || value > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "hex_rounds must be 0 (one launch) .. 1024");
       q->hex_rounds = int(value);

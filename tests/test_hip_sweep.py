@@ -108,7 +108,19 @@ def test_sweep_equals_separate_handles_and_fast_mode(oracle, golden_dir):
         sweep.set_option("arithmetic", arith)
         got = sweep.scan_and_optimize(grids, ulp)
         roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
+        if arith:
+            sweep.set_option("segments", -1)  # the sequential elimination first: same bits as a single handle's
         vecs = sweep.eigenvector(roots)
+        if arith:
+            # the FMA build's default for a sweep: segment-parallel eigenvectors (transfer matrices per segment, the
+            # boundary system, the fill); same tolerance contract as a single handle's (1e-7 of the largest component)
+            sweep.set_option("segments", 0)
+            sweep.stats(reset=True)
+            seg = sweep.eigenvector(roots)
+            assert sweep.stats()["segment_fallbacks"] == 0
+            for k in range(len(cfg)):
+                for a, b in zip(seg[k][1], vecs[k][1]):
+                    assert np.max(np.abs(a - b)) <= 1e-7 * np.max(np.abs(b)), (k, np.max(np.abs(a - b)) / np.max(np.abs(b)))
         for k, o in enumerate(solvers):
             h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
             h.set_option("arithmetic", arith)
