@@ -380,8 +380,12 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 
-/* Counters and options of a sweep ("arithmetic", "hex_lanes", "hex_rounds", "eigen_layout", "steps_bytes_max" as below; the
- * staging cap defaults to 16 GiB for a sweep). */
+/* Counters and options of a sweep ("arithmetic", "hex_lanes", "hex_rounds", "eigen_layout", "steps_bytes_max",
+ * "seg_growth_log2", "coupling_tile" as for a solver / post-processing handle; the staging cap defaults to 16 GiB for a
+ * sweep).  "segments": 0 (default) = in the FMA build every eigenvector pass and every discriminant batch of at most
+ * 3072 frequencies per class (the refinement rounds) goes through segment transfer matrices, with the tolerances of
+ * "arithmetic" = 1 (a pass in which a transfer matrix outgrows the guard is redone sequentially and counted in
+ * segment_fallbacks); -1 = never.  The parity build never takes that path. */
 int storm_sweep_stats(storm_sweep* sweep, storm_stats* out, int reset);
 int storm_sweep_set_option(storm_sweep* sweep, const char* key, int64_t value);
 

@@ -57,7 +57,8 @@ SDEV double chain_step(double acc, double2 lo, double2 hi) {
 template <bool ELL0, bool SCALED>
 __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                    const double* __restrict__ steps, double* __restrict__ det_out,
-                                                   long long* __restrict__ exp_out) {
+                                                   long long* __restrict__ exp_out, const SystemDev* __restrict__ table,
+                                                   const int* __restrict__ sys_index) {
   __shared__ double sh[64];
   const int tid = threadIdx.x;
   const int sub = tid & 15;
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
     M4 a;
 #pragma unroll
     for (int e = 0; e < 16; ++e) a.v[e] = sh[(tid & 48) + e];
-    const double det = close_determinant<ELL0>(s, freq[fi_raw], a);
+    // (several systems per launch: the boundary rows are those of the frequency's own system; `s` carries the common
+    // number of steps, which for a segment-parallel evaluation is the number of segments, not the system's intervals)
+    const double det = table ? close_determinant<ELL0>(table[sys_index[fi_raw]], freq[fi_raw], a) : close_determinant<ELL0>(s, freq[fi_raw], a);
     if constexpr (SCALED) {
       // mantissa in [0.5, 1) like frexp; zero, inf and NaN keep exponent 0
       const unsigned long long bits = (unsigned long long)__double_as_longlong(det);
@@ -127,19 +130,19 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
 }
 
 hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
-                        double* det_out, hipStream_t stream) {
+                        double* det_out, hipStream_t stream, const SystemDev* table, const int* sys_index) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 3) / 4);
-  if (ell0) chain_kernel<true, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr);
-  else chain_kernel<false, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr);
+  if (ell0) chain_kernel<true, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index);
+  else chain_kernel<false, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index);
   return hipGetLastError();
 }
 hipError_t launch_chain_scaled(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
                                double* mantissa_out, long long* exponent_out, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 3) / 4);
-  if (ell0) chain_kernel<true, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out);
-  else chain_kernel<false, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out);
+  if (ell0) chain_kernel<true, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr);
+  else chain_kernel<false, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr);
   return hipGetLastError();
 }
 

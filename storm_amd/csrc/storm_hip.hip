@@ -822,7 +822,7 @@ void det_device(storm_solver* s, const double* d_freq, size_t n, double* d_out, 
       hip_check(g_launch_build[s->arith][s->scheme](make_args(s, d_freq + off, m, s->d_steps.p, st, flags)), "build_steps launch");
       tb.stop();
       ScopedTimer tc(s, st, STORM_KERNEL_CHAIN);
-      hip_check((s->arith ? storm_fast::launch_chain : storm::launch_chain)(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st), "chain launch");
+      hip_check((s->arith ? storm_fast::launch_chain : storm::launch_chain)(s->sys, s->ell0, d_freq + off, m, s->d_steps.p, d_out + off, st, nullptr, nullptr), "chain launch");
       tc.stop();
       count_launch(s, 2);
     }
@@ -2241,9 +2241,15 @@ namespace {
 
 constexpr int kSetClasses = 3;  // 0: ell == 0, 1: ell != 0 with bitwise-uniform m*rot, 2: general
 constexpr size_t kSetPad = 4;   // det_hex: an aligned group of 4 frequencies (one wave at 16 lanes each) is one system's
+// FMA build: class batches up to this size take the segment path (set_det).  The card holds ~12 288 sixteen-lane groups
+// at once (one det_hex wave round): cutting chains only pays while a batch has fewer chains than that (measured: 7476
+// frequencies in two segments each 3.1 ms, 5420 in two segments 2.3 ms, as whole chains in det_hex 1.85 / 1.45 ms).
+constexpr size_t kSetSegMaxBatch = 3072, kSetSegGroups = 12288;
 
 inline bool set_class_ell0(int c) { return c == 0; }
 inline bool set_class_uniform(int c) { return c != 2; }
+// segment-parallel evaluation (FMA build only: it re-associates the ordered product)
+inline bool set_uses_segments(const storm_sweep* q) { return q->arith == 1 && q->segments >= 0 && q->n_int >= 64; }
 
 void set_check_flags(storm_sweep* q) {
   q->h_flags.reserve(1);
@@ -2290,6 +2296,26 @@ void set_det(storm_sweep* q, const std::vector<const double*>& x, const std::vec
   for (int c = 0; c < kSetClasses; ++c) {
     const size_t first = poff[q->cls_begin[c]], n = poff[q->cls_begin[c + 1]] - first;
     if (!n) continue;
+    // FMA build, batches that leave the card idle as one chain per frequency (refinement rounds: a few thousand
+    // brackets at most): segment transfer matrices in one launch, then the ordered product + boundary elimination over
+    // the segments with every frequency's own boundary rows (the single-handle version is det_segments)
+    if (set_uses_segments(q) && n <= kSetSegMaxBatch) {
+      const size_t n_int = q->n_int;
+      const size_t want = std::max<size_t>(2, kSetSegGroups / n);
+      size_t seg_len = ((n_int + want - 1) / want + 15) / 16 * 16;
+      seg_len = std::max<size_t>(seg_len, 32);
+      const size_t n_seg = (1 + (n_int - 1 + seg_len - 1) / seg_len + 3) / 4 * 4;  // the first interval is a segment of its own
+      q->d_partials.reserve(n * n_seg * 16, q->stream);
+      LaunchArgs a = set_args(q, c, first, n, q->d_partials.p);
+      a.n_seg = int(n_seg); a.seg_len = int(seg_len);
+      hip_check(g_launch_seg_product[q->arith][q->scheme](a), "seg_product launch");
+      SystemDev reduced = q->h_table[q->cls_begin[c]];
+      reduced.n_int = n_seg;
+      hip_check(storm_fast::launch_chain(reduced, set_class_ell0(c), q->d_freq.p + first, n, q->d_partials.p, q->d_det.p + first,
+                                         q->stream, q->d_table.p, q->d_sys.p + first), "chain launch");
+      q->stats.launches += 2;
+      continue;
+    }
     hip_check(g_launch_hex[q->arith][q->scheme](set_args(q, c, first, n, q->d_det.p + first)), "det_hex launch");
     q->stats.launches += 1;
   }
@@ -2366,8 +2392,6 @@ size_t set_eigen_reserve(storm_sweep* q, size_t n) {
   // (step matrices and factors of the sequential elimination, 2 MB per mode: reserved where that path is taken)
   return chunk;
 }
-
-bool set_uses_segments(const storm_sweep* q) { return q->arith == 1 && q->segments >= 0 && q->n_int >= 64; }
 
 // Segment-parallel eigenvectors of one chunk (FMA build; the single-handle version is eigen_segments): transfer matrices
 // of every (mode, segment) pair, the reference's elimination + back-substitution on the system of the segment boundaries

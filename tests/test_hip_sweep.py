@@ -106,21 +106,31 @@ def test_sweep_equals_separate_handles_and_fast_mode(oracle, golden_dir):
     for arith in (0, 1):
         sweep = sweep_from_oracle(solvers)
         sweep.set_option("arithmetic", arith)
+        if arith:
+            sweep.set_option("segments", -1)  # the kernels a single handle can be pinned to: same bits
         got = sweep.scan_and_optimize(grids, ulp)
         roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
-        if arith:
-            sweep.set_option("segments", -1)  # the sequential elimination first: same bits as a single handle's
         vecs = sweep.eigenvector(roots)
         if arith:
-            # the FMA build's default for a sweep: segment-parallel eigenvectors (transfer matrices per segment, the
-            # boundary system, the fill); same tolerance contract as a single handle's (1e-7 of the largest component)
+            # the FMA build's default for a sweep: small batches (these scans, every refinement round) and all
+            # eigenvectors go through segment transfer matrices.  The tolerance contract of a single handle: the same
+            # brackets, roots within 1e-10, eigenvectors within 1e-7 of their largest component.
             sweep.set_option("segments", 0)
             sweep.stats(reset=True)
+            got_seg = sweep.scan_and_optimize(grids, ulp)
             seg = sweep.eigenvector(roots)
             assert sweep.stats()["segment_fallbacks"] == 0
             for k in range(len(cfg)):
-                for a, b in zip(seg[k][1], vecs[k][1]):
-                    assert np.max(np.abs(a - b)) <= 1e-7 * np.max(np.abs(b)), (k, np.max(np.abs(a - b)) / np.max(np.abs(b)))
+                a, b = got_seg[k][0], got[k][0]
+                assert len(a) == len(b) and got_seg[k][2] == got[k][2], k
+                for x, y in zip(a, b):
+                    assert abs(x["root"] - y["root"]) <= 1e-10 * abs(y["root"]), (k, x["root"], y["root"])
+                    assert y["lo_x"] <= x["root"] <= y["hi_x"] or abs(x["root"] - y["root"]) <= 1e-10 * abs(y["root"])
+                scale = np.max(np.abs(got[k][1]))
+                assert np.max(np.abs(got_seg[k][1] - got[k][1])) <= 1e-8 * scale, k
+                for u, v in zip(seg[k][1], vecs[k][1]):
+                    assert np.max(np.abs(u - v)) <= 1e-7 * np.max(np.abs(v)), (k, np.max(np.abs(u - v)) / np.max(np.abs(v)))
+            sweep.set_option("segments", -1)
         for k, o in enumerate(solvers):
             h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
             h.set_option("arithmetic", arith)
