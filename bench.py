@@ -47,8 +47,8 @@ FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "collo
 # planes with 8-byte loads, so the figure is an upper bound.  The algorithmic bytes are ~2.7 MB (planes once + 16 B per
 # frequency); the surplus is one fetch of the planes per XCD L2 and, in the FMA build, 20 B/lane of register spills.
 TRAFFIC = {("det_hex<colloc8>", 10000, 0): 2 * 10872.8e3 + 156.25e3,          # profiles/r01_pmc_det_hex_colloc8.txt
-           ("det_hex<colloc4>", 100000, 1): 2 * 11397.2e3 + 14602.6e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
-           ("det_hex<colloc4>", 100000, 0): 2 * 8445.33e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
+           ("det_hex<colloc4>", 100000, 1): 2 * 11397.1e3 + 14609.7e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
+           ("det_hex<colloc4>", 100000, 0): 2 * 8445.35e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
 PEAK_FP64_TFLOPS = 78.6     # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz) = the dense FP64 MFMA peak
 UNFUSED_TFLOPS = 38.1       # measured chip-wide ceiling of separate v_mul_f64 / v_add_f64 (tools/fp64_microbench.hip)
 HBM_PEAK_GBS = 8000.0
