@@ -452,7 +452,7 @@ SDEV void seg_round_build(const SystemDev& s, size_t i0, int sub, double f, cons
 }
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
-__global__ __launch_bounds__(64) void seg_product_kernel(SystemDev s0, const double* __restrict__ freq, int n_seg, int seg_len,
+__global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void seg_product_kernel(SystemDev s0, const double* __restrict__ freq, int n_seg, int seg_len,
                                                          double* __restrict__ partial, unsigned long long* __restrict__ growth,
                                                          int* __restrict__ flags, const SystemDev* __restrict__ table,
                                                          const int* __restrict__ sys_index) {
