@@ -130,6 +130,15 @@ def test_sweep_equals_separate_handles_and_fast_mode(oracle, golden_dir):
                 assert np.max(np.abs(got_seg[k][1] - got[k][1])) <= 1e-8 * scale, k
                 for u, v in zip(seg[k][1], vecs[k][1]):
                     assert np.max(np.abs(u - v)) <= 1e-7 * np.max(np.abs(v)), (k, np.max(np.abs(u - v)) / np.max(np.abs(v)))
+            # the guard: with the growth bound at 2^0 every transfer matrix is "too large", the pass is redone by the
+            # sequential elimination and counted -- same bits as with the segment path switched off
+            sweep.set_option("seg_growth_log2", 0)
+            sweep.stats(reset=True)
+            guarded = sweep.eigenvector(roots)
+            assert sweep.stats()["segment_fallbacks"] == sum(r.size for r in roots)
+            for k in range(len(cfg)):
+                assert same_bits(guarded[k][1], vecs[k][1]) and same_bits(guarded[k][0], vecs[k][0]), k
+            sweep.set_option("seg_growth_log2", 24)
             sweep.set_option("segments", -1)
         for k, o in enumerate(solvers):
             h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
