@@ -321,7 +321,7 @@ void storm_shard_bounds(size_t n, size_t n_parts, size_t k, size_t* lo, size_t* 
  * slabs the library allocates as the need grows (4 GiB doubling to 32 GiB for blocks of 64 MiB and more, smaller ones for
  * smaller blocks; pinned host memory likewise) and keeps until storm_memory_cache_trim, below three quarters of the
  * device's memory in all.  storm_memory_cache_limit switches to separately allocated blocks of which the given number
- * of bytes may stay cached.  storm_memory_cache_stats counts idle bytes (free slab space included).
+ * of bytes may stay cached.  storm_memory_cache_stats counts what a trim would give back (listed blocks, slabs nothing is carved from).
  * A caller that used storm_det_batch_device with its own stream must synchronise that stream before destroying the
  * handle. */
 int storm_memory_cache_trim(void);                                            /* give everything cached back to HIP */

@@ -250,9 +250,12 @@ class MemoryCache {
   static int arena_key(bool pinned, int dev, int band) { return pinned ? band : kBands + dev * kBands + band; }
   static bool arena_key_pinned(int k) { return k < kBands; }
   static int arena_key_dev(int k) { return k < kBands ? 0 : (k - kBands) / kBands; }
+  // idle slab memory: what a trim would hand back (slabs nothing is carved from; the holes of a slab in use stay)
   size_t arena_free_locked(bool pinned) const {
     size_t f = 0;
-    for (auto& kv : arenas_) if (arena_key_pinned(kv.first) == pinned) for (auto& a : kv.second) f += a.free_bytes;
+    for (auto& kv : arenas_)
+      if (arena_key_pinned(kv.first) == pinned)
+        for (auto& a : kv.second) if (a.free_bytes == a.size) f += a.size;
     return f;
   }
   size_t arena_bytes_locked(bool pinned, int dev) {
