@@ -4,8 +4,8 @@ The reference runs one rayon task per scan frequency (src/dynamic_interface.rs:1
 `collect()` barriers there are the only global points.  Here every rank evaluates a contiguous
 slice of the frequency grid plus ONE halo point on the right, so every adjacent pair (i, i+1) is
 owned by exactly the rank that owns i; brackets are refined where they are found and the
-(tiny, latency-bound) bracket lists are gathered with one all_gather of counts and one of padded
-records -- RCCL over xGMI on GPUs (`backend="nccl"`), gloo in the CPU tests.  There is no
+(tiny, latency-bound) bracket lists are gathered with one all_gather of padded records behind a
+header row (a second one only if a rank found more than GATHER_CAP) -- RCCL over xGMI on GPUs (`backend="nccl"`), gloo in the CPU tests.  There is no
 collective inside the data path.
 """
 import numpy as np
@@ -40,21 +40,45 @@ def unpack(rec):
             for r in rec]
 
 
-def gather_brackets(local_records, invalid, device):
-    """all_gather of per-rank bracket records -> (global records in ascending order, any_invalid)."""
+GATHER_CAP = 64  # bracket records per rank that fit the first exchange (a scan finds a few dozen modes in all)
+
+
+def _all_gather_rows(buf, device):
+    """all_gather of one equally shaped float64 array per rank -> array [world, *buf.shape] on the host."""
     world = dist.get_world_size()
-    count = torch.tensor([local_records.shape[0], 1 if invalid else 0], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count)
-    counts = torch.stack(counts).cpu().numpy()
-    cap = max(1, int(counts[:, 0].max()))
-    buf = torch.zeros((cap, RECORD), dtype=torch.float64, device=device)
-    if local_records.shape[0]:
-        buf[:local_records.shape[0]] = torch.from_numpy(local_records).to(device)
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
-    parts = [bufs[r][:int(counts[r, 0])].cpu().numpy() for r in range(world)]
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, RECORD)), bool(counts[:, 1].any())
+    t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device)
+    try:
+        dist.all_gather_into_tensor(out, t)
+    except (RuntimeError, NotImplementedError, AttributeError):  # a backend without the single-tensor form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        out = torch.stack(parts)
+    return out.cpu().numpy()
+
+
+def gather_brackets(local_records, invalid, device):
+    """all_gather of per-rank bracket records -> (global records in ascending order, any_invalid).
+
+    ONE collective in the usual case: every rank sends GATHER_CAP padded records behind a header row (count, invalid
+    flag); only if some rank found more is a second exchange made, sized by the largest count."""
+    n = local_records.shape[0]
+    buf = np.zeros((GATHER_CAP + 1, RECORD))
+    buf[0, 0], buf[0, 1] = float(n), 1.0 if invalid else 0.0
+    if n:
+        buf[1:1 + min(n, GATHER_CAP)] = local_records[:GATHER_CAP]
+    got = _all_gather_rows(buf, device)
+    counts = got[:, 0, 0].astype(np.int64)
+    any_invalid = bool(got[:, 0, 1].any())
+    if counts.max(initial=0) > GATHER_CAP:
+        cap = int(counts.max())
+        big = np.zeros((cap, RECORD))
+        big[:n] = local_records
+        got = _all_gather_rows(big, device)
+        parts = [got[r, :counts[r]] for r in range(got.shape[0])]
+    else:
+        parts = [got[r, 1:1 + counts[r]] for r in range(got.shape[0])]
+    return (np.concatenate(parts, axis=0) if parts else np.zeros((0, RECORD))), any_invalid
 
 
 def sharded_scan_and_optimize(solver, freqs, ulp, device="cpu"):
@@ -107,17 +131,15 @@ def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None
         after_refine(my)
     # second exchange: every rank's count follows from the deal, so one all_gather of padded records is enough
     cap = max(1, -(-rec.shape[0] // world))
-    buf = torch.zeros((cap, RECORD), dtype=torch.float64)
+    buf = np.zeros((cap, RECORD))
     if my:
-        buf[:len(my)] = torch.from_numpy(pack(my, 0))
-    buf = buf.to(device)
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
+        buf[:len(my)] = pack(my, 0)
+    got = _all_gather_rows(buf, device)
     out = np.zeros((rec.shape[0], RECORD))
     for r in range(world):
         idx = deal(rec.shape[0], world, r)
         if idx:
-            out[idx] = bufs[r][:len(idx)].cpu().numpy()
+            out[idx] = got[r, :len(idx)]
     return unpack(out), any_inv, my
 
 
