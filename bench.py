@@ -170,14 +170,18 @@ def main():
     freqs = host.linspace(1.0, 25.0, N_FREQ)
     lo_idx, mine = D.local_slice(freqs, world, rank) if world > 1 else (0, freqs)
 
-    vec_buf = np.empty(64 * (n_int + 1) * 4)  # the caller's eigenvector block, reused from scan to scan
+    def result_block(n_doubles):
+        """The caller's eigenvector block: pinned host memory, so that the library copies into it by DMA."""
+        return torch.empty(n_doubles, dtype=torch.float64, pin_memory=True).numpy()
+
+    vec_buf = result_block(64 * (n_int + 1) * 4)  # reused from scan to scan
 
     def eigenvectors(brackets):
         nonlocal vec_buf
         if brackets:
             need = len(brackets) * (n_int + 1) * 4
             if vec_buf.size < need:
-                vec_buf = np.empty(need)
+                vec_buf = result_block(need)
             h.eigenvector(np.array([b["root"] for b in brackets]), out=vec_buf)
 
     def one_scan():

@@ -135,7 +135,9 @@ int storm_optimize_brackets(storm_solver* solver, storm_bracket* brackets, size_
 
 /* Replaces the `eigenvector` closure = determinant_with_upper + UpperResult::eigenvectors
  * (src/dynamic_interface.rs:213-219, src/solver.rs:100-131,271-433), batched over modes.
- * vec_out is [n][(n_int+1)*4], element [i*4+k] = y_{k+1}(x_i); det_out (may be NULL) is [n]. */
+ * vec_out is [n][(n_int+1)*4], element [i*4+k] = y_{k+1}(x_i); det_out (may be NULL) is [n].  If vec_out is pinned host
+ * memory (hipHostMalloc / hipHostRegister) the eigenvectors are copied into it by DMA, otherwise through the library's
+ * pinned staging block and a host copy. */
 int storm_eigenvector_batch(storm_solver* solver, const double* freq, size_t n, double* det_out, double* vec_out);
 
 /* ---- Post-processing of found modes (the caller of the scan path: `post-process`, src/main.rs:878-899) ----

@@ -310,3 +310,25 @@ def test_buffers_of_every_size_band_are_recycled_through_the_slabs(oracle, oracl
     f = oracle.linspace(1.0, 24.0, 300)
     assert same_bits(h.det(f), o.det(f, threads=16))
     h.close()
+
+
+def test_eigenvectors_into_a_pinned_result_block(oracle, oracle_models):
+    # a caller's pinned (page-locked) result block is filled by DMA, a pageable one through the library's staging block:
+    # same bits either way, and only the requested part of the block is written
+    import torch
+    model = oracle_models("zams")
+    o = oracle.Solver(model, 2, 0, "colloc4", model.field("r_coord"))
+    h = hip_from_oracle(o)
+    roots = oracle.linspace(3.0, 12.0, 7)
+    rdet, rvec = o.eigenvector(roots, threads=8)
+    length = (o.n_int + 1) * 4
+    pinned = torch.full((9 * length,), -1.0, dtype=torch.float64).pin_memory().numpy()
+    det, vec = h.eigenvector(roots, out=pinned)
+    assert same_bits(det, rdet) and same_bits(vec, rvec)
+    assert np.all(pinned[7 * length:] == -1.0)
+    pageable = np.full(9 * length, -1.0)
+    det2, vec2 = h.eigenvector(roots, out=pageable)
+    assert same_bits(det2, rdet) and same_bits(vec2, rvec) and np.all(pageable[7 * length:] == -1.0)
+    with pytest.raises(ValueError):
+        h.eigenvector(roots, out=np.empty(5))
+    h.close()
