@@ -134,10 +134,9 @@ SDEV double fast_recip(double x) {
 
 // FMA build: the same adjugate inverse, evaluated through the twelve 2x2 sub-determinants of the row pairs (0,1) and (2,3)
 // (Laplace expansion; each 3x3 cofactor of the reference's formula is a 3-term combination of them), ~100 instructions
-// instead of ~210.  Re-associates the cofactors, so it is not offered in the parity build.  Returns SCALE * a^-1 (the factor
+// instead of ~210.  Re-associates the cofactors, so it is not offered in the parity build.  Returns scale * a^-1 (the factor
 // goes into the reciprocal of the determinant).
-template <int SCALE = 1>
-SDEV M4 m4_inverse_fast(const M4& a, bool& ok) {
+SDEV M4 m4_inverse_fast(const M4& a, bool& ok, double scale = 1.0) {
   auto e = [&](int r, int c) { return a.v[c * 4 + r]; };
   const double s0 = e(0, 0) * e(1, 1) - e(1, 0) * e(0, 1), s1 = e(0, 0) * e(1, 2) - e(1, 0) * e(0, 2);
   const double s2 = e(0, 0) * e(1, 3) - e(1, 0) * e(0, 3), s3 = e(0, 1) * e(1, 2) - e(1, 1) * e(0, 2);
@@ -147,7 +146,7 @@ SDEV M4 m4_inverse_fast(const M4& a, bool& ok) {
   const double c1 = e(2, 0) * e(3, 2) - e(3, 0) * e(2, 2), c0 = e(2, 0) * e(3, 1) - e(3, 0) * e(2, 1);
   const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
   ok = ok && (det != 0.0);
-  const double q = double(SCALE) * fast_recip(det);
+  const double q = scale * fast_recip(det);
   M4 o;
   auto put = [&](int r, int c, double v) { o.v[c * 4 + r] = v * q; };
   put(0, 0, e(1, 1) * c5 - e(1, 2) * c4 + e(1, 3) * c3);
@@ -172,7 +171,7 @@ SDEV M4 m4_inverse_fast(const M4& a, bool& ok) {
 
 SDEV M4 m4_inverse(const M4& a, bool& ok) {
 #ifdef STORM_FAST_BUILD
-  return m4_inverse_fast<1>(a, ok);
+  return m4_inverse_fast(a, ok);
 #endif
   const double* m = a.v;
   M4 o;

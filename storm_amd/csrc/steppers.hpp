@@ -55,21 +55,51 @@ SDEV M4 m4_mul_aa(const M4& a, const M4& b) { return m4_mul(a, b); }
 SDEV M4 m4_mul_ax(const M4& a, const M4& x) { return m4_mul(a, x); }
 #endif
 
+// FMA build: colloc_jump returns the weighted stage sum WITHOUT its common factor c (jump = c * S), and step_matrix folds c
+// into the scaled inverse: (c S - I)^-1 = (S - I/c)^-1 / c.  Saves one matrix scaling per interval.
+template <int SCHEME>
+constexpr double colloc_jump_factor() {
+  return SCHEME == kColloc2 ? 0.5 : SCHEME == kColloc4 ? 0.25 : SCHEME == kColloc6 ? 5. / 36. : kW1 / 2.;
+}
+
+#ifdef STORM_FAST_BUILD
+// (I - c x)^-1 = (-1/c) (x - I/c)^-1: the factor goes into the reciprocal of the determinant
+SDEV M4 m4_inverse_shifted(const M4& x, double c, bool& ok) {
+  M4 st = x;
+  st.v[0] -= 1.0 / c; st.v[5] -= 1.0 / c; st.v[10] -= 1.0 / c; st.v[15] -= 1.0 / c;
+  return m4_inverse_fast(st, ok, -1.0 / c);
+}
+#endif
+
 template <int SCHEME>
 SDEV M4 colloc_jump(const M4* a, bool& ok) {
   if constexpr (SCHEME == kColloc2) {
+#ifdef STORM_FAST_BUILD
+    return a[0];
+#endif
     return m4_scale(a[0], 0.5);
   } else if constexpr (SCHEME == kColloc4) {
     const M4 a2a1 = m4_mul_aa(a[1], a[0]);
+#ifdef STORM_FAST_BUILD
+    const M4 k2 = m4_mul(m4_inverse_shifted(a2a1, -1. / 12., ok), m4_add(a[1], m4_scale(a2a1, kC2_2)));
+#else
     const M4 k2 = m4_mul(m4_inverse(m4_eye_plus(m4_scale(a2a1, 1. / 12.)), ok), m4_add(a[1], m4_scale(a2a1, kC2_2)));
+#endif
     const M4 k1 = m4_add(a[0], m4_scale(m4_mul_ax(a[0], k2), kC2_1));
+#ifdef STORM_FAST_BUILD
+    return m4_add(k1, k2);
+#endif
     return m4_scale(m4_add(k1, k2), 0.25);
   } else if constexpr (SCHEME == kColloc6) {
     constexpr double d12 = -2. / 3. * kC3_1, d13 = -1. / 3. * kC3_1, d21 = 5. / 12. * kC3_1;
     constexpr double d23 = -5. / 12. * kC3_1, d31 = 1. / 3. * kC3_1, d32 = 2. / 3. * kC3_1;
     const M4 a2a1 = m4_mul_aa(a[1], a[0]);
     const M4 a3a1 = m4_mul_aa(a[2], a[0]);
+#ifdef STORM_FAST_BUILD
+    const M4 inv1 = m4_inverse_shifted(a2a1, d12 * d21, ok);
+#else
     const M4 inv1 = m4_inverse(m4_eye_minus(m4_scale(a2a1, d12 * d21)), ok);
+#endif
     const M4 o2 = m4_mul(inv1, m4_sub(a[1], m4_scale(a2a1, d21)));
     const M4 l2 = m4_mul(inv1, m4_sub(m4_scale(a[1], d23), m4_scale(a2a1, d13 * d21)));
     const M4 f3 = m4_sub(m4_scale(a[2], d32), m4_scale(a3a1, d12 * d31));
@@ -78,11 +108,18 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 k3 = m4_mul(m4_inverse(l3, ok), o3);
     const M4 k2 = m4_sub(o2, m4_mul(l2, k3));
     const M4 k1 = m4_mul_ax(a[0], m4_sub(m4_eye_minus(m4_scale(k2, d12)), m4_scale(k3, d13)));
+#ifdef STORM_FAST_BUILD
+    return m4_add(m4_add(k1, k3), m4_scale(k2, (2. / 9.) / (5. / 36.)));
+#endif
     return m4_add(m4_add(m4_scale(k1, 5. / 36.), m4_scale(k2, 2. / 9.)), m4_scale(k3, 5. / 36.));
   } else {
     static_assert(SCHEME == kColloc8, "collocation scheme expected");
     const M4 a2a1 = m4_mul_aa(a[1], a[0]), a3a1 = m4_mul_aa(a[2], a[0]), a4a1 = m4_mul_aa(a[3], a[0]);
+#ifdef STORM_FAST_BUILD
+    const M4 inv2 = m4_inverse_shifted(a2a1, kD21 * kD12, ok);
+#else
     const M4 inv2 = m4_inverse(m4_eye_minus(m4_scale(a2a1, kD21 * kD12)), ok);
+#endif
     const M4 u23 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD23), m4_scale(a2a1, kD21 * kD13)));
     const M4 u24 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD24), m4_scale(a2a1, kD21 * kD14)));
     const M4 r2 = m4_mul(inv2, m4_sub(a[1], m4_scale(a2a1, kD21)));
@@ -99,6 +136,9 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 k2 = m4_sub(m4_sub(r2, m4_mul(u24, k4)), m4_mul(u23, k3));
     const M4 k1 = m4_sub(m4_sub(m4_sub(a[0], m4_mul_ax(m4_scale(a[0], kD14), k4)), m4_mul_ax(m4_scale(a[0], kD13), k3)),
                          m4_mul_ax(m4_scale(a[0], kD12), k2));
+#ifdef STORM_FAST_BUILD
+    return m4_add(m4_add(k1, k4), m4_scale(m4_add(k2, k3), kW2 / kW1));
+#endif
     return m4_add(m4_add(m4_add(m4_scale(k1, kW1 / 2.), m4_scale(k2, kW2 / 2.)), m4_scale(k3, kW2 / 2.)),
                   m4_scale(k4, kW1 / 2.));
   }
@@ -153,6 +193,16 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
     return m4_exp(magnus_omega<SCHEME>(a));
   } else {
     const M4 jump = colloc_jump<SCHEME>(a, ok);
+#ifdef STORM_FAST_BUILD
+    // (-right^-1) * left with left = right + 2 I, i.e. -I - 2 right^-1: no product (same matrix, re-associated); with
+    // jump = c S, right = c (S - I/c) and right^-1 = (S - I/c)^-1 / c
+    constexpr double c = colloc_jump_factor<SCHEME>();
+    M4 r = jump;
+    r.v[0] -= 1.0 / c; r.v[5] -= 1.0 / c; r.v[10] -= 1.0 / c; r.v[15] -= 1.0 / c;
+    M4 t = m4_inverse_fast(r, ok, -2.0 / c);
+    t.v[0] = t.v[0] - 1.0; t.v[5] = t.v[5] - 1.0; t.v[10] = t.v[10] - 1.0; t.v[15] = t.v[15] - 1.0;
+    return t;
+#else
     M4 l, r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -160,13 +210,6 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
       l.v[i] = jump.v[i] + id;
       r.v[i] = jump.v[i] - id;
     }
-#ifdef STORM_FAST_BUILD
-    // (-right^-1) * left with left = right + 2 I, i.e. -I - 2 right^-1: no product (same matrix, re-associated)
-    M4 t = m4_inverse_fast<-2>(r, ok);
-    t.v[0] = t.v[0] - 1.0; t.v[5] = t.v[5] - 1.0; t.v[10] = t.v[10] - 1.0; t.v[15] = t.v[15] - 1.0;
-    (void)l;
-    return t;
-#else
     return m4_mul(m4_neg(m4_inverse(r, ok)), l);
 #endif
   }
