@@ -167,6 +167,64 @@ SDEV M4 m4_inverse_fast(const M4& a, bool& ok, double scale = 1.0) {
   put(3, 3, e(2, 0) * s3 - e(2, 1) * s1 + e(2, 2) * s0);
   return o;
 }
+
+// FMA build: a = L U without row exchanges (L unit lower triangular; d = reciprocals of U's diagonal), ~45 instructions,
+// and a^-1 b for one column in 16.  The stage matrices of the collocation schemes are I + O((dx/x)^2) and c S - I with
+// S = O(dx/x): diagonally dominant everywhere but in the first few intervals next to the centre.  lu4_factor returns false
+// unless every multiplier is <= 1 in magnitude -- the factorisation partial pivoting would have produced, element growth
+// <= 8 -- and the caller then takes the adjugate inverse instead (also for a zero or NaN pivot: the comparisons fail).
+struct Lu4 {
+  double l10, l20, l30, l21, l31, l32;
+  double u01, u02, u03, u12, u13, u23;
+  double d0, d1, d2, d3;
+};
+SDEV bool lu4_factor(const M4& a, Lu4& f) {
+  auto e = [&](int r, int c) { return a.v[c * 4 + r]; };
+  f.d0 = fast_recip(e(0, 0));
+  f.u01 = e(0, 1); f.u02 = e(0, 2); f.u03 = e(0, 3);
+  f.l10 = e(1, 0) * f.d0; f.l20 = e(2, 0) * f.d0; f.l30 = e(3, 0) * f.d0;
+  const double b11 = e(1, 1) - f.l10 * f.u01, b12 = e(1, 2) - f.l10 * f.u02, b13 = e(1, 3) - f.l10 * f.u03;
+  const double b21 = e(2, 1) - f.l20 * f.u01, b22 = e(2, 2) - f.l20 * f.u02, b23 = e(2, 3) - f.l20 * f.u03;
+  const double b31 = e(3, 1) - f.l30 * f.u01, b32 = e(3, 2) - f.l30 * f.u02, b33 = e(3, 3) - f.l30 * f.u03;
+  f.d1 = fast_recip(b11);
+  f.u12 = b12; f.u13 = b13;
+  f.l21 = b21 * f.d1; f.l31 = b31 * f.d1;
+  const double c22 = b22 - f.l21 * f.u12, c23 = b23 - f.l21 * f.u13;
+  const double c32 = b32 - f.l31 * f.u12, c33 = b33 - f.l31 * f.u13;
+  f.d2 = fast_recip(c22);
+  f.u23 = c23;
+  f.l32 = c32 * f.d2;
+  const double e33 = c33 - f.l32 * f.u23;
+  f.d3 = fast_recip(e33);
+  return __builtin_fabs(f.l10) <= 1.0 && __builtin_fabs(f.l20) <= 1.0 && __builtin_fabs(f.l30) <= 1.0 &&
+         __builtin_fabs(f.l21) <= 1.0 && __builtin_fabs(f.l31) <= 1.0 && __builtin_fabs(f.l32) <= 1.0 &&
+         __builtin_fabs(f.d3) < __builtin_inf();
+}
+// x <- a^-1 x
+SDEV void lu4_solve(const Lu4& f, double* x) {
+  const double y0 = x[0];
+  const double y1 = x[1] - f.l10 * y0;
+  const double y2 = (x[2] - f.l20 * y0) - f.l21 * y1;
+  const double y3 = ((x[3] - f.l30 * y0) - f.l31 * y1) - f.l32 * y2;
+  const double x3 = y3 * f.d3;
+  const double x2 = (y2 - f.u23 * x3) * f.d2;
+  const double x1 = ((y1 - f.u12 * x2) - f.u13 * x3) * f.d1;
+  const double x0 = (((y0 - f.u01 * x1) - f.u02 * x2) - f.u03 * x3) * f.d0;
+  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
+}
+// a^-1 b, falling back on the adjugate inverse where the factorisation would need row exchanges
+SDEV M4 m4_solve(const M4& a, const M4& b, bool& ok) {
+  Lu4 f;
+  M4 x;
+  if (lu4_factor(a, f)) {
+    x = b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lu4_solve(f, &x.v[j * 4]);
+  } else {
+    x = m4_mul(m4_inverse_fast(a, ok), b);
+  }
+  return x;
+}
 #endif
 
 SDEV M4 m4_inverse(const M4& a, bool& ok) {

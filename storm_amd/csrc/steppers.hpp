@@ -81,15 +81,17 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
   } else if constexpr (SCHEME == kColloc4) {
     const M4 a2a1 = m4_mul_aa(a[1], a[0]);
 #ifdef STORM_FAST_BUILD
-    const M4 k2 = m4_mul(m4_inverse_shifted(a2a1, -1. / 12., ok), m4_add(a[1], m4_scale(a2a1, kC2_2)));
+    // k2 = (I + a2a1/12)^-1 rhs = 12 z with (12 I + a2a1) z = rhs, solved by LU; k1 + k2 = a1 + 12 (z + c1 a1 z)
+    M4 st = a2a1;
+    st.v[0] += 12.0; st.v[5] += 12.0; st.v[10] += 12.0; st.v[15] += 12.0;
+    const M4 z = m4_solve(st, m4_add(a[1], m4_scale(a2a1, kC2_2)), ok);
+    const M4 w = m4_add(z, m4_scale(m4_mul_ax(a[0], z), kC2_1));
+    return m4_add(a[0], m4_scale(w, 12.0));
 #else
     const M4 k2 = m4_mul(m4_inverse(m4_eye_plus(m4_scale(a2a1, 1. / 12.)), ok), m4_add(a[1], m4_scale(a2a1, kC2_2)));
-#endif
     const M4 k1 = m4_add(a[0], m4_scale(m4_mul_ax(a[0], k2), kC2_1));
-#ifdef STORM_FAST_BUILD
-    return m4_add(k1, k2);
-#endif
     return m4_scale(m4_add(k1, k2), 0.25);
+#endif
   } else if constexpr (SCHEME == kColloc6) {
     constexpr double d12 = -2. / 3. * kC3_1, d13 = -1. / 3. * kC3_1, d21 = 5. / 12. * kC3_1;
     constexpr double d23 = -5. / 12. * kC3_1, d31 = 1. / 3. * kC3_1, d32 = 2. / 3. * kC3_1;
