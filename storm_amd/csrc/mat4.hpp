@@ -212,18 +212,25 @@ SDEV void lu4_solve(const Lu4& f, double* x) {
   const double x0 = (((y0 - f.u01 * x1) - f.u02 * x2) - f.u03 * x3) * f.d0;
   x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
 }
-// a^-1 b, falling back on the adjugate inverse where the factorisation would need row exchanges
-SDEV M4 m4_solve(const M4& a, const M4& b, bool& ok) {
+// x[k] <- a^-1 x[k], falling back on the adjugate inverse where the factorisation would need row exchanges
+template <int N>
+SDEV void m4_solve_n(const M4& a, M4 (&x)[N], bool& ok) {
   Lu4 f;
-  M4 x;
   if (lu4_factor(a, f)) {
-    x = b;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lu4_solve(f, &x.v[j * 4]);
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lu4_solve(f, &x[k].v[j * 4]);
   } else {
-    x = m4_mul(m4_inverse_fast(a, ok), b);
+    const M4 inv = m4_inverse_fast(a, ok);
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] = m4_mul(inv, x[k]);
   }
-  return x;
+}
+SDEV M4 m4_solve(const M4& a, const M4& b, bool& ok) {
+  M4 x[1] = {b};
+  m4_solve_n<1>(a, x, ok);
+  return x[0];
 }
 #endif
 

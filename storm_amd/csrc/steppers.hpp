@@ -62,15 +62,6 @@ constexpr double colloc_jump_factor() {
   return SCHEME == kColloc2 ? 0.5 : SCHEME == kColloc4 ? 0.25 : SCHEME == kColloc6 ? 5. / 36. : kW1 / 2.;
 }
 
-#ifdef STORM_FAST_BUILD
-// (I - c x)^-1 = (-1/c) (x - I/c)^-1: the factor goes into the reciprocal of the determinant
-SDEV M4 m4_inverse_shifted(const M4& x, double c, bool& ok) {
-  M4 st = x;
-  st.v[0] -= 1.0 / c; st.v[5] -= 1.0 / c; st.v[10] -= 1.0 / c; st.v[15] -= 1.0 / c;
-  return m4_inverse_fast(st, ok, -1.0 / c);
-}
-#endif
-
 template <int SCHEME>
 SDEV M4 colloc_jump(const M4* a, bool& ok) {
   if constexpr (SCHEME == kColloc2) {
@@ -97,17 +88,19 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     constexpr double d23 = -5. / 12. * kC3_1, d31 = 1. / 3. * kC3_1, d32 = 2. / 3. * kC3_1;
     const M4 a2a1 = m4_mul_aa(a[1], a[0]);
     const M4 a3a1 = m4_mul_aa(a[2], a[0]);
-#ifdef STORM_FAST_BUILD
-    const M4 inv1 = m4_inverse_shifted(a2a1, d12 * d21, ok);
-#else
+    // (FMA build: solving this first system, two right-hand sides, by LU as well takes det_hex past 256 registers, its
+    // second wave per SIMD, and costs more than it saves)
     const M4 inv1 = m4_inverse(m4_eye_minus(m4_scale(a2a1, d12 * d21)), ok);
-#endif
     const M4 o2 = m4_mul(inv1, m4_sub(a[1], m4_scale(a2a1, d21)));
     const M4 l2 = m4_mul(inv1, m4_sub(m4_scale(a[1], d23), m4_scale(a2a1, d13 * d21)));
     const M4 f3 = m4_sub(m4_scale(a[2], d32), m4_scale(a3a1, d12 * d31));
     const M4 o3 = m4_sub(m4_sub(a[2], m4_scale(a3a1, d31)), m4_mul(f3, o2));
     const M4 l3 = m4_sub(m4_eye_minus(m4_scale(a3a1, d13 * d31)), m4_mul(f3, l2));
+#ifdef STORM_FAST_BUILD
+    const M4 k3 = m4_solve(l3, o3, ok);
+#else
     const M4 k3 = m4_mul(m4_inverse(l3, ok), o3);
+#endif
     const M4 k2 = m4_sub(o2, m4_mul(l2, k3));
     const M4 k1 = m4_mul_ax(a[0], m4_sub(m4_eye_minus(m4_scale(k2, d12)), m4_scale(k3, d13)));
 #ifdef STORM_FAST_BUILD
@@ -118,10 +111,22 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     static_assert(SCHEME == kColloc8, "collocation scheme expected");
     const M4 a2a1 = m4_mul_aa(a[1], a[0]), a3a1 = m4_mul_aa(a[2], a[0]), a4a1 = m4_mul_aa(a[3], a[0]);
 #ifdef STORM_FAST_BUILD
-    const M4 inv2 = m4_inverse_shifted(a2a1, kD21 * kD12, ok);
+    // the stage systems are solved by LU (m4_solve_n) instead of inverse + product
+    M4 s2[3] = {m4_sub(m4_scale(a[1], kD23), m4_scale(a2a1, kD21 * kD13)),
+                m4_sub(m4_scale(a[1], kD24), m4_scale(a2a1, kD21 * kD14)), m4_sub(a[1], m4_scale(a2a1, kD21))};
+    m4_solve_n<3>(m4_eye_minus(m4_scale(a2a1, kD21 * kD12)), s2, ok);
+    const M4 u23 = s2[0], u24 = s2[1], r2 = s2[2];
+    const M4 l32 = m4_sub(m4_scale(a[2], kD32), m4_scale(a3a1, kD31 * kD12));
+    M4 s3[2] = {m4_sub(m4_sub(m4_scale(a[2], kD34), m4_scale(a3a1, kD31 * kD14)), m4_mul(l32, u24)),
+                m4_sub(m4_sub(a[2], m4_scale(a3a1, kD31)), m4_mul(l32, r2))};
+    m4_solve_n<2>(m4_sub(m4_eye_minus(m4_scale(a3a1, kD31 * kD13)), m4_mul(l32, u23)), s3, ok);
+    const M4 u34 = s3[0], r3 = s3[1];
+    const M4 l42 = m4_sub(m4_scale(a[3], kD42), m4_scale(a4a1, kD41 * kD12));
+    const M4 l43 = m4_sub(m4_sub(m4_scale(a[3], kD43), m4_scale(a4a1, kD41 * kD13)), m4_mul(l42, u23));
+    const M4 k4 = m4_solve(m4_sub(m4_sub(m4_eye_minus(m4_scale(a4a1, kD41 * kD14)), m4_mul(l42, u24)), m4_mul(l43, u34)),
+                           m4_sub(m4_sub(m4_sub(a[3], m4_scale(a4a1, kD41)), m4_mul(l42, r2)), m4_mul(l43, r3)), ok);
 #else
     const M4 inv2 = m4_inverse(m4_eye_minus(m4_scale(a2a1, kD21 * kD12)), ok);
-#endif
     const M4 u23 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD23), m4_scale(a2a1, kD21 * kD13)));
     const M4 u24 = m4_mul(inv2, m4_sub(m4_scale(a[1], kD24), m4_scale(a2a1, kD21 * kD14)));
     const M4 r2 = m4_mul(inv2, m4_sub(a[1], m4_scale(a2a1, kD21)));
@@ -134,6 +139,7 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 inv4 = m4_inverse(
         m4_sub(m4_sub(m4_eye_minus(m4_scale(a4a1, kD41 * kD14)), m4_mul(l42, u24)), m4_mul(l43, u34)), ok);
     const M4 k4 = m4_mul(inv4, m4_sub(m4_sub(m4_sub(a[3], m4_scale(a4a1, kD41)), m4_mul(l42, r2)), m4_mul(l43, r3)));
+#endif
     const M4 k3 = m4_sub(r3, m4_mul(u34, k4));
     const M4 k2 = m4_sub(m4_sub(r2, m4_mul(u24, k4)), m4_mul(u23, k3));
     const M4 k1 = m4_sub(m4_sub(m4_sub(a[0], m4_mul_ax(m4_scale(a[0], kD14), k4)), m4_mul_ax(m4_scale(a[0], kD13), k3)),
@@ -187,6 +193,28 @@ SDEV M4 magnus_omega(const M4* a) {
   }
 }
 
+#ifdef STORM_FAST_BUILD
+// FMA build, collocation schemes: with jump = c S the transfer matrix is (-right^-1) * left with right = c S - I and
+// left = right + 2 I, i.e. -I - 2 right^-1 = -I - (2/c) (S - I/c)^-1: no product (same matrix, re-associated).
+// colloc_shifted returns S - I/c, step_from_shifted inverts it.  (Factoring S - I/c and applying the solve to the columns
+// of det_col's running product instead was measured: 150 fewer instructions per interval and no faster -- the 20-deep
+// dependent chain per step and four more v_rcp_f64 cost what the adjugate inverse did.  DESIGN.md section 12.)
+template <int SCHEME>
+SDEV M4 colloc_shifted(const M4* a, bool& ok) {
+  constexpr double c = colloc_jump_factor<SCHEME>();
+  M4 r = colloc_jump<SCHEME>(a, ok);
+  r.v[0] -= 1.0 / c; r.v[5] -= 1.0 / c; r.v[10] -= 1.0 / c; r.v[15] -= 1.0 / c;
+  return r;
+}
+template <int SCHEME>
+SDEV M4 step_from_shifted(const M4& r, bool& ok) {
+  constexpr double c = colloc_jump_factor<SCHEME>();
+  M4 t = m4_inverse_fast(r, ok, -2.0 / c);
+  t.v[0] = t.v[0] - 1.0; t.v[5] = t.v[5] - 1.0; t.v[10] = t.v[10] - 1.0; t.v[15] = t.v[15] - 1.0;
+  return t;
+}
+#endif
+
 // The transfer matrix of one interval.  `ok` goes false if a collocation stage matrix is
 // singular (the reference panics there).
 template <int SCHEME>
@@ -194,17 +222,10 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
   if constexpr (scheme_is_magnus(SCHEME)) {
     return m4_exp(magnus_omega<SCHEME>(a));
   } else {
-    const M4 jump = colloc_jump<SCHEME>(a, ok);
 #ifdef STORM_FAST_BUILD
-    // (-right^-1) * left with left = right + 2 I, i.e. -I - 2 right^-1: no product (same matrix, re-associated); with
-    // jump = c S, right = c (S - I/c) and right^-1 = (S - I/c)^-1 / c
-    constexpr double c = colloc_jump_factor<SCHEME>();
-    M4 r = jump;
-    r.v[0] -= 1.0 / c; r.v[5] -= 1.0 / c; r.v[10] -= 1.0 / c; r.v[15] -= 1.0 / c;
-    M4 t = m4_inverse_fast(r, ok, -2.0 / c);
-    t.v[0] = t.v[0] - 1.0; t.v[5] = t.v[5] - 1.0; t.v[10] = t.v[10] - 1.0; t.v[15] = t.v[15] - 1.0;
-    return t;
+    return step_from_shifted<SCHEME>(colloc_shifted<SCHEME>(a, ok), ok);
 #else
+    const M4 jump = colloc_jump<SCHEME>(a, ok);
     M4 l, r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
