@@ -357,9 +357,10 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *                 sign pattern / bracket indices on the BASELINE configs, roots within 1e-10 relative.
  *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels,
  *           3 force the 4-lanes-per-frequency fused kernel, 4 force the 16/32-lanes-per-frequency fused kernel
- *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default): whole wave rounds of a large batch at 4 lanes (the
- *                column-owner kernel det_col), the rest at 16 or 32, whichever packs the GPU's wave slots better; 4, 16, 32
- *                force one (same bits)
+ *   "hex_lanes": lanes per frequency of the path-4 kernel: 0 (default): a large batch goes out as ONE launch of column
+ *                owners (4 lanes per frequency) for most of it and 16-lane groups for the rest (det_mix), a smaller one
+ *                at 16 or 32 lanes, whichever packs the GPU's wave slots better; 4, 16, 32 force one (same bits in the
+ *                parity build); -1..-99 (tuning knob) force det_mix with that percentage of column owners
  *   "hex_rounds": the path-4 kernel sends a batch that is larger than the GPU's wave slots in pieces of this many
  *                 wave rounds (default 1), so that kernels of other handles get dispatched between the pieces
  *                 instead of after the whole batch; 0 = one launch

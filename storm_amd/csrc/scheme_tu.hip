@@ -101,14 +101,32 @@ static size_t col_wave_slots() {
 // 5.9 vs 6.9, Colloc4 23.5 vs 24.3 | 12.6 vs 13.3, Magnus2/4/6 2-3 % | 5-7 % faster, Magnus8 72.9 vs 78.1 | 48.3 vs 52.8;
 // NOT for Colloc6 (58.1 vs 43.8 | 33.8 vs 25.1: the mixed kernel needs more than 256 registers and loses the second
 // wave per SIMD) and Colloc8 (119.9 vs 108.2 | 64.3 vs 64.4).
+// Column-owner workgroups det_mix gives this batch (0: det_mix does not take it).
 template <bool ELL0, bool UNIFORM>
-static bool mix_takes(const LaunchArgs& a) {
-  if (STORM_SCHEME == kColloc6 || STORM_SCHEME == kColloc8) return false;
+static size_t mix_col_blocks(const LaunchArgs& a) {
+  if (STORM_SCHEME == kColloc6 || STORM_SCHEME == kColloc8) return 0;
+  if (a.table != nullptr || a.sys.n_int < 4 || a.n < 32) return 0;
+  if (a.hex_lanes < 0) return a.n * size_t(-a.hex_lanes) / 100 / 16;  // tuning knob: -p = p % column owners, whatever n
+  if (a.hex_lanes != 0) return 0;
   // worth it once the column-owner part alone fills the chip and leaves a det_hex part behind it.  (Measured at 10^5
   // frequencies, FMA build, Colloc4: 80 % column-owner 19.75 ms, whole wave rounds of them (49 %) 20.67 ms, none 20.92 ms.)
-  // At 62 000 frequencies the mix LOSES 3 %, at 2*10^5 and 10^6 it gains 5 %: from 30 wave slots' worth of frequencies.
-  return a.hex_lanes == 0 && a.table == nullptr && a.sys.n_int >= 4 && a.n >= 30 * col_wave_slots<ELL0, UNIFORM>();
+  // From 30 wave slots' worth of frequencies (~92 000): 80 % of them.  From 18 (~55 000): as many column-owner waves as
+  // are resident at once, less 5 % -- a few waves past one resident set start when the first finish and double the launch
+  // (61 500 frequencies, FMA build Colloc4: 3075 waves 12.2 ms, 2690 waves 11.2 ms; det_hex alone 12.2 ms).  Measured
+  // with scripts/mix_split_timing.py (share of column owners against time): 56 000 frequencies 11.2 -> 9.6 ms, 68 000
+  // 12.9 -> 11.7, 80 000 15.1 -> 13.8, 90 000 16.4 -> 15.6.  Below that the long waves outlast the det_hex part.
+  // The 18-slot rule only for kernels with three or more waves per SIMD: with two (parity Colloc4, Magnus2/4/6) it gains
+  // 1-3 % at 50-70 000 frequencies and loses 4-7 % at 40 000 (scripts/mix_auto_check.py).  Known soft spot of the 80 %
+  // rule: 86 000 frequencies of a two-wave kernel are 2.1 resident sets of column-owner waves and come out 2-4 % behind
+  // det_hex (10^5: 2-3 % ahead); cutting the count back to whole sets did not change that, so it is left alone.
+  const size_t slots = col_wave_slots<ELL0, UNIFORM>();
+  const size_t want = std::min(a.n * 4 / 5 / 16, (a.n - 1) / 16);
+  if (a.n >= 30 * slots) return want;
+  if (slots >= 3 * 1024 && a.n >= 18 * slots) return std::min(want, slots - slots / 20);
+  return 0;
 }
+template <bool ELL0, bool UNIFORM>
+static bool mix_takes(const LaunchArgs& a) { return mix_col_blocks<ELL0, UNIFORM>(a) > 0; }
 template <bool ELL0, bool UNIFORM>
 static hipError_t launch_hex_v(const LaunchArgs& a) {
   int lpf = a.hex_lanes;
@@ -117,21 +135,28 @@ static hipError_t launch_hex_v(const LaunchArgs& a) {
   // start as the long column-owner waves finish and give the launch a short-wave end (det_mix_kernel).  Not for sweeps (a
   // wave of 16 frequencies may straddle systems) and not when the caller pinned the lane count to 16 or 32; hex_lanes = 4
   // forces the column-owner kernel alone.
-  if ((lpf == 0 || lpf == 4) && a.table == nullptr && a.sys.n_int >= 4) {
+  if ((lpf <= 0 || lpf == 4) && a.table == nullptr && a.sys.n_int >= 4) {
     if (lpf == 4) {
       det_col_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)((a.n + 15) / 16), 64, 0, a.stream>>>(a.sys, a.freq, a.n, a.out, a.flags);
       return hipGetLastError();
     }
-    if (mix_takes<ELL0, UNIFORM>(a)) {
-      const size_t col_blocks = std::min(a.n * 4 / 5 / 16, (a.n - 1) / 16);
+    const size_t col_blocks = mix_col_blocks<ELL0, UNIFORM>(a);
+    if (col_blocks > 0) {
       const size_t hex_blocks = (a.n - col_blocks * 16 + 3) / 4;
       det_mix_kernel<STORM_SCHEME, ELL0, UNIFORM><<<(unsigned)(col_blocks + hex_blocks), 64, 0, a.stream>>>(
           a.sys, a.freq, a.n, a.out, a.flags, (unsigned)col_blocks);
       return hipGetLastError();
     }
   }
-  if (lpf != 16 && lpf != 32)
+  if (lpf != 16 && lpf != 32) {
     lpf = hex_cost<ELL0, UNIFORM, 32>(a.n, a.sys.n_int) < hex_cost<ELL0, UNIFORM, 16>(a.n, a.sys.n_int) ? 32 : 16;
+    // The whole-rounds model holds where waves run in lockstep: one wave per SIMD at any size, more waves per SIMD only
+    // while the 16-lane waves are less than 1.5 resident sets.  Beyond that the dispatcher refills SIMDs continuously
+    // and 32 lanes only cost their longer ordered product (2*10^4 frequencies, tams: Colloc4 parity 5.13 ms with 16
+    // lanes, 6.20 with 32; Magnus2/4/6 alike in both builds; FMA Colloc4 at 29 000: 3.90 vs 4.59).
+    const size_t slots16 = hex_wave_slots<ELL0, UNIFORM, 16>();
+    if (lpf == 32 && slots16 > 1024 && (a.n + 3) / 4 * 2 >= slots16 * 3) lpf = 16;
+  }
   // (Tried and measured no gain, round 2: sending the whole wave rounds at 16 lanes and the remainder as a second launch
   // at 32 lanes.  10^5 frequencies are 25000 waves on 2048 slots = 12.2 rounds; the launch takes 12.2 rounds' time, not
   // 13 -- waves drift apart and the dispatcher refills SIMDs continuously -- so the split only added a launch.)

@@ -1352,7 +1352,8 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
       if (value < 0) fail(STORM_ERR_INVALID_ARGUMENT, "hex_min_n must be >= 0");
       s->hex_min_n = size_t(value);
     } else if (k == "hex_lanes") {
-      if (value != 0 && value != 4 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 4, 16 or 32");
+      if (value != 0 && value != 4 && value != 16 && value != 32 && !(value < 0 && value > -100))
+        fail(STORM_ERR_INVALID_ARGUMENT, "hex_lanes must be 0 (auto), 4, 16 or 32");
       s->hex_lanes = int(value);
     } else if (k == "hex_rounds") {
       if (value < 0 || value > 1024) fail(STORM_ERR_INVALID_ARGUMENT, "hex_rounds must be 0 (one launch) .. 1024");
