@@ -89,8 +89,10 @@ def test_mode_id(host, host_models, known_answers, name):
 # ---------------------------------------------------------------------------------------------
 def each_det_path(h):
     """Forces every discriminant kernel in turn (all must give the same bits): fused, split, quad,
-    hex with 16 and with 32 lanes per frequency, the column-owner kernel (4 lanes); restores the automatic choice afterwards."""
-    for path, lanes in ((1, 0), (2, 0), (3, 0), (4, 16), (4, 32), (4, 4)):
+    hex with 16 and with 32 lanes per frequency, the column-owner kernel (4 lanes), det_mix with 50 % column owners
+    (hex_lanes = -50: the launch large batches get; Colloc6/8 and batches under 32 frequencies fall back to det_hex);
+    restores the automatic choice afterwards."""
+    for path, lanes in ((1, 0), (2, 0), (3, 0), (4, 16), (4, 32), (4, 4), (4, -50)):
         h.set_option("path", path)
         h.set_option("hex_lanes", lanes)
         yield f"path {path} lanes {lanes}"
