@@ -80,6 +80,46 @@ def test_fast_rotation_and_inverse_grid(oracle, golden_dir):
         assert np.array_equal(np.signbit(got), np.signbit(ref))
 
 
+@pytest.mark.parametrize("scheme", ["colloc2", "colloc4", "colloc6", "colloc8"])
+def test_fast_collocation_on_the_largest_fixture(oracle, oracle_models, scheme):
+    # joel: the finest grid of the fixtures; the collocation schemes of the FMA build solve their stage systems by LU with
+    # the adjugate inverse as the fall-back next to the centre (mat4.hpp: lu4_factor / m4_solve_n), both are walked here
+    # On this grid the discriminant of ell = 3 is ill-conditioned beyond the contract: ONE ulp of the frequency moves the
+    # reference's own value by up to 1e-2 of the local scale (ell = 1: 5e-11), so no re-association can stay within 1e-9
+    # there.  The bar is therefore the larger of DET_TOL and 32 x that one-ulp sensitivity, measured with the oracle
+    # (19 204 intervals each round their matrices: measured 1.4e-9 = 27 one-ulp steps at ell = 1, 1.7e-3 at ell = 3).
+    model = oracle_models("joel")
+    for ell in (1, 3):
+        o = oracle.Solver(model, ell, 0, scheme, model.field("r_coord"))
+        h = hip_from_oracle(o, 1)
+        f = oracle.linspace(1.0, 25.0, 96)
+        ref = o.det(f, threads=16)
+        scale = local_scale(ref)
+        one_ulp = np.max(np.abs(o.det(np.nextafter(f, 100.0), threads=16) - ref) / scale)
+        tol = max(DET_TOL, 32.0 * one_ulp)
+        for path in (2, 4):
+            h.set_option("path", path)
+            got = h.det(f)
+            assert np.all(np.abs(got - ref) <= tol * scale), (ell, path, np.max(np.abs(got - ref) / scale), one_ulp)
+            clear = np.abs(ref) > 2.0 * tol * scale
+            assert np.array_equal(np.signbit(got[clear]), np.signbit(ref[clear])), (ell, path)
+
+
+@pytest.mark.parametrize("scheme", ["colloc4", "colloc6", "magnus4"])
+def test_fast_differential_rotation(oracle, golden_dir, scheme):
+    # non-uniform rotation: the frequency terms (and, in the FMA build, their reciprocal) are evaluated per point
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_zams.npz"))
+    x = model.field("r_coord")
+    model.set_field("rot", 0.05 + 0.1 * np.exp(-3.0 * x) - 0.02 * x)
+    o = oracle.Solver(model, 2, 1, scheme, x)
+    h = hip_from_oracle(o, 1)
+    f = oracle.linspace(1.0, 20.0, 200)
+    ref = o.det(f, threads=16)
+    got = h.det(f)
+    assert np.all(np.abs(got - ref) <= DET_TOL * local_scale(ref)), np.max(np.abs(got - ref) / local_scale(ref))
+    assert np.array_equal(np.signbit(got), np.signbit(ref))
+
+
 def test_default_arithmetic_is_parity(oracle, oracle_models):
     import storm_amd
     model = oracle_models("zams")
