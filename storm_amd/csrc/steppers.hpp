@@ -152,6 +152,18 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
   }
 }
 
+// Commutators whose factors are (combinations of) point matrices: the products skip the structural zeros in the FMA build.
+// SA / SB: the left / right factor of [a, b] has the point matrices' zero pattern.
+template <bool SA, bool SB>
+SDEV M4 magnus_commutator(const M4& a, const M4& b) {
+#ifdef STORM_FAST_BUILD
+  constexpr unsigned ZA = SA ? kPointMatrixZeros : 0u, ZB = SB ? kPointMatrixZeros : 0u;
+  return m4_sub(m4_mul_sparse<ZA, ZB>(a, b), m4_mul_sparse<ZB, ZA>(b, a));
+#else
+  return m4_commutator(a, b);
+#endif
+}
+
 template <int SCHEME>
 SDEV M4 magnus_omega(const M4* a) {
   if constexpr (SCHEME == kMagnus2) {
@@ -159,14 +171,14 @@ SDEV M4 magnus_omega(const M4* a) {
   } else if constexpr (SCHEME == kMagnus4) {
     const M4 b1 = m4_scale(m4_add(a[0], a[1]), 0.5);
     const M4 b2 = m4_scale(m4_sub(a[1], a[0]), 0.5 * kC2_2);
-    return m4_sub(b1, m4_commutator(b1, b2));
+    return m4_sub(b1, magnus_commutator<true, true>(b1, b2));
   } else if constexpr (SCHEME == kMagnus6) {
     constexpr double ten_three = 10. / 3.;
     const M4& b1 = a[1];
     const M4 b2 = m4_scale(m4_sub(a[2], a[0]), kC3_3 * ten_three);
     const M4 b3 = m4_scale(m4_add(m4_sub(a[2], m4_scale(a[1], 2.)), a[0]), ten_three);
-    const M4 c1 = m4_commutator(b1, b2);
-    const M4 c2 = m4_scale(m4_commutator(b1, m4_add(m4_scale(b3, 2.), c1)), -1. / 60.);
+    const M4 c1 = magnus_commutator<true, true>(b1, b2);
+    const M4 c2 = m4_scale(magnus_commutator<true, false>(b1, m4_add(m4_scale(b3, 2.), c1)), -1. / 60.);
     return m4_add(m4_add(b1, m4_scale(b3, 1. / 12.)),
                   m4_scale(m4_commutator(m4_add(m4_sub(m4_scale(b1, -20.), b3), c1), m4_add(b2, c2)), 1. / 240.));
   } else {
@@ -179,10 +191,10 @@ SDEV M4 magnus_omega(const M4* a) {
     const M4 b4 = m4_add(m4_scale(a1a, kB4A1A), m4_scale(a2a, kB4A2A));
     const M4 b1p = m4_add(b1, m4_scale(b3, 1. / 28.));
     const M4 b2p = m4_add(b2, m4_scale(b4, 3. / 28.));
-    const M4 s1 = m4_scale(m4_commutator(b1p, b2p), -1. / 28.);
-    const M4 r1 = m4_scale(m4_commutator(b1, m4_add(m4_scale(b3, -1. / 14.), s1)), 1. / 3.);
+    const M4 s1 = m4_scale(magnus_commutator<true, true>(b1p, b2p), -1. / 28.);
+    const M4 r1 = m4_scale(magnus_commutator<true, false>(b1, m4_add(m4_scale(b3, -1. / 14.), s1)), 1. / 3.);
     const M4 s2 = m4_commutator(m4_add(b1p, s1), m4_add(b2p, r1));
-    const M4 s2p = m4_commutator(b2, s1);
+    const M4 s2p = magnus_commutator<true, false>(b2, s1);
     const M4 r2 = m4_commutator(m4_add(b1, m4_scale(s1, 5. / 4.)),
                                 m4_add(m4_add(m4_scale(b3, 2.0), s2), m4_scale(s2p, 0.5)));
     const M4 base = m4_add(b1, m4_scale(b3, 1. / 12.));
