@@ -295,6 +295,9 @@ SDEV int exp_scaling_exponent(double norm) {
 // exp(A) by scaling and squaring with the 18-term Taylor polynomial of Bader, Blanes &
 // Casas evaluated with 5 products (reference src/linalg/storage.rs:402-470).  The
 // polynomial terms are accumulated left to right including the zero coefficients.
+// SPARSE_IN (FMA build only): `a` has the point matrices' zero pattern (Magnus2: Omega is the midpoint matrix itself), so
+// the first two products skip it.
+template <bool SPARSE_IN = false>
 SDEV M4 m4_exp(M4 a) {
   constexpr double T[5][5] = {
       {0., -0.10036558103014462, -0.00802924648241157, -0.00089213849804573, 0.},
@@ -318,8 +321,14 @@ SDEV M4 m4_exp(M4 a) {
     const double sc = __builtin_ldexp(1.0, -exponent);
     a = m4_scale(a, sc);
   }
+#ifdef STORM_FAST_BUILD
+  constexpr unsigned kZ = SPARSE_IN ? kPointMatrixZeros : 0u;
+  const M4 a2 = m4_mul_sparse<kZ, kZ>(a, a);
+  const M4 a3 = m4_mul_sparse<0u, kZ>(a2, a);
+#else
   const M4 a2 = m4_mul(a, a);
   const M4 a3 = m4_mul(a2, a);
+#endif
   const M4 a6 = m4_mul(a3, a3);
   // b_i = T[i][0] I + T[i][1] A + T[i][2] A^2 + T[i][3] A^3 + T[i][4] A^6, formed where it is consumed (five of them at
   // once are 160 registers)

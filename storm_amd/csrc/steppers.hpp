@@ -232,7 +232,7 @@ SDEV M4 step_from_shifted(const M4& r, bool& ok) {
 template <int SCHEME>
 SDEV M4 step_matrix(const M4* a, bool& ok) {
   if constexpr (scheme_is_magnus(SCHEME)) {
-    return m4_exp(magnus_omega<SCHEME>(a));
+    return m4_exp<SCHEME == kMagnus2>(magnus_omega<SCHEME>(a));
   } else {
 #ifdef STORM_FAST_BUILD
     return step_from_shifted<SCHEME>(colloc_shifted<SCHEME>(a, ok), ok);
