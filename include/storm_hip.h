@@ -351,8 +351,10 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
 
 /* Options.  Every "path" is bit-identical; only "arithmetic" = 1 changes results (to rounding).
  *   "arithmetic": 0 (default) parity build: separate multiply and add in the reference's order, results
- *                 bit-identical to the reference; 1 fast build: the same expressions with FMA contraction
- *                 (v_fma_f64), ~2x arithmetic ceiling.  Fast-mode contract (tests/test_hip_fast_mode.py):
+ *                 bit-identical to the reference; 1 fast build: the same mathematics with FMA contraction
+ *                 (v_fma_f64) and re-associated where that saves instructions (adjugate through 2x2 minors, stage
+ *                 systems by LU, reciprocals by Newton steps, segment-parallel products: DESIGN.md section 5), ~3x
+ *                 the parity build's throughput.  Fast-mode contract (tests/test_hip_fast_mode.py):
  *                 |det_fast - det_ref| <= 1e-9 * max|det_ref| over the neighbouring grid points, identical
  *                 sign pattern / bracket indices on the BASELINE configs, roots within 1e-10 relative.
  *   "path": 0 auto, 1 force lane-per-frequency fused kernel, 2 force build-steps + ordered-product kernels,
