@@ -1,5 +1,5 @@
 """Runs storm_coupling_matrices a few times on M modes (default 512) for rocprofv3 passes.
-usage: profile_coupling.py [M] [reps]"""
+usage: profile_coupling.py [M] [reps] [arithmetic]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from storm_amd import host, ffi
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+arith = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 model = host.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_tams.npz"))
 model.set_rotation_constant(0.1)
 grid = model.field("r_coord")
@@ -25,6 +26,7 @@ x = grid
 metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x ** 2,
           "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}
 raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
+raw.set_option("arithmetic", arith)
 f, e, fl = freqs[sel], ells[sel], np.ascontiguousarray(fields[sel])
 for _ in range(reps):
     out = raw.coupling_matrices(e, f, fl, 0, metric)
