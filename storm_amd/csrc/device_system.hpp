@@ -52,6 +52,12 @@ struct GlobalCoef {
   size_t plane, stride;
   SDEV double operator()(int field, int j) const { return base[field * plane + j * stride]; }
 };
+// ... from the interval-major copy of a single solver (types.hpp, aos_pitch): base = its row of this lane's interval ...
+template <int P>
+struct AosCoef {
+  const double* __restrict__ base;
+  SDEV double operator()(int field, int j) const { return base[field * P + j]; }
+};
 // ... or from a tile the wave staged in LDS: rows (field*P + j) of W intervals, this lane's interval `sub`.
 template <int P, int W>
 struct LdsCoef {

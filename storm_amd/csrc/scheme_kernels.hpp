@@ -295,6 +295,19 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 // L*acc is evaluated term by term in the reference's gemm order, so the bits are the same.  It has a quarter of det_hex's
 // waves, each four times as long: the launcher uses it for whole wave rounds of large batches and sends the remainder
 // through det_hex (launch_hex in scheme_tu.hip).
+// Where the column-owner body takes its coefficients from the interval-major copy (AosCoef: 23 address instructions and
+// half the load instructions less per interval for Colloc4) instead of the planes.  Same values, same bits.  Measured on
+// one box, both trees alternating, 10^5 frequencies on tams (ms, planes -> copy): parity Colloc2 10.49 -> 10.28, Colloc4
+// 23.56 -> 22.92, Magnus2 24.47 -> 24.72, Magnus6 40.7 -> 40.6, Magnus8 73.1 -> 83.9 (!); FMA build Colloc2 5.58 -> 5.42,
+// Colloc4 10.71 -> 10.27, Magnus2 14.95 -> 14.73, Magnus6 25.57 -> 24.95, Magnus8 49.4 -> 45.8.
+__host__ __device__ constexpr bool col_reads_aos(int scheme) {
+#ifdef STORM_FAST_BUILD
+  return true;
+#else
+  return scheme == kColloc2 || scheme == kColloc4;
+#endif
+}
+
 constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
@@ -315,7 +328,16 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
   const double* __restrict__ mats = lds + g * kColGroup;
   for (size_t i0 = 0; i0 < n_int; i0 += 4) {
     // rows are padded past n_int with copies of the last interval, so no clamping is needed
-    const M4 l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + q, f, ut, ok);
+    M4 l;
+    if constexpr (col_reads_aos(SCHEME)) {
+      // the coefficients come from the interval-major copy: one address per lane, 16-byte loads at immediate offsets
+      constexpr int kP = scheme_points(SCHEME);
+      const AosCoef<kP> cf{static_cast<const double*>(
+          __builtin_assume_aligned(s.tab + kNumFields * s.plane + (i0 + q) * (size_t)aos_pitch(kP), 16))};
+      l = interval_step_from<SCHEME, ELL0, UNIFORM>(cf, s.lambda, f, ut, ok);
+    } else {
+      l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + q, f, ut, ok);
+    }
     __syncthreads();  // previous round's matrices have been consumed
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {  // row-major: row rr = {L(rr,0..3)}

@@ -627,6 +627,17 @@ void build_planes(const storm_system_desc& d, double* t, bool& uniform, double& 
       }
 }
 
+// The interval-major copy behind the planes (types.hpp, aos_pitch): `t` holds planes_elems + aos_elems doubles.
+size_t aos_elems(size_t n_int, size_t p) { return padded_stride(n_int) * size_t(aos_pitch(int(p))); }
+void build_aos(size_t n_int, size_t p, double* t) {
+  const size_t stride = padded_stride(n_int), pitch = size_t(aos_pitch(int(p))), rows = size_t(kNumFields) * p;
+  double* aos = t + planes_elems(n_int, p);
+  for (size_t i = 0; i < stride; ++i) {
+    for (size_t r = 0; r < rows; ++r) aos[i * pitch + r] = t[r * stride + i];
+    for (size_t r = rows; r < pitch; ++r) aos[i * pitch + r] = 0.0;
+  }
+}
+
 void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
 
 // The pinned staging block also carried the planes to the device in storm_solver_create: before it can go back to
@@ -1258,9 +1269,10 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     hip_check(hipGetDevice(&s->device), "hipGetDevice");
     s->scheme = d->scheme;
     double rotm0 = 0.0;
-    const size_t tab_elems = planes_elems(d->n_int, d->p);
+    const size_t tab_elems = planes_elems(d->n_int, d->p) + aos_elems(d->n_int, d->p);
     s->h_vec.reserve(tab_elems);  // built in the (cached) pinned block the upload is staged from
     build_planes(*d, s->h_vec.p, s->uniform, rotm0);
+    build_aos(d->n_int, d->p, s->h_vec.p);
     const double ell = double(d->ell);
     s->ell0 = (ell == 0.0);
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0

@@ -28,6 +28,11 @@ enum Field : int {
   kNumFields
 };
 
+// A single solver (not the systems of a sweep) keeps a second copy of the planes behind them, interval-major: the
+// kNumFields * p values of interval i in consecutive doubles at tab + kNumFields * plane + i * aos_pitch(p), row order
+// field * p + j.  The column-owner kernels read it: one address per lane and interval, immediate offsets for the rest.
+__host__ __device__ constexpr int aos_pitch(int p) { return (kNumFields * p + 1) / 2 * 2; }  // doubles; rows 16-B aligned
+
 struct SystemDev {
   const double* tab;   // kNumFields planes
   size_t plane;        // doubles per plane (= p * stride)
