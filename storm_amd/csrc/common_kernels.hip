@@ -301,6 +301,27 @@ __global__ __launch_bounds__(64) void refine_step_kernel(BracketDev* __restrict_
   br[k] = b;
 }
 
+// One thread per interval: reads of a plane row are coalesced across the threads, each thread writes its interval's row.
+__global__ __launch_bounds__(256) void aos_copy_kernel(double* __restrict__ tab, size_t sys_elems, size_t stride, int rows, int pitch) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= stride) return;
+  const double* __restrict__ soa = tab + (size_t)blockIdx.y * sys_elems;
+  double* __restrict__ dst = tab + (size_t)blockIdx.y * sys_elems + (size_t)rows * stride + i * (size_t)pitch;
+  for (int r = 0; r < rows; ++r) dst[r] = soa[(size_t)r * stride + i];
+  for (int r = rows; r < pitch; ++r) dst[r] = 0.0;
+}
+hipError_t launch_aos_copy(double* tab, size_t n_sys, size_t sys_elems, size_t stride, int p, hipStream_t stream) {
+  if (n_sys == 0 || stride == 0) return hipSuccess;
+  for (size_t k0 = 0; k0 < n_sys; k0 += 65535) {  // grid.y limit
+    const unsigned cnt = (unsigned)std::min<size_t>(65535, n_sys - k0);
+    aos_copy_kernel<<<dim3((unsigned)((stride + 255) / 256), cnt, 1), 256, 0, stream>>>(tab + k0 * sys_elems, sys_elems, stride,
+                                                                                         kNumFields * p, aos_pitch(p));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count, int* flags, hipStream_t stream) {
   if (n < 2) return hipSuccess;
   swap_count_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(det, n, block_count, flags);

@@ -16,6 +16,9 @@ inline size_t swap_blocks(size_t n) { return n < 2 ? 0 : (n - 1 + 1023) / 1024; 
 }  // namespace storm
 
 // Scheme-independent launchers, one set per arithmetic build (see types.hpp).
+// launch_aos_copy fills the interval-major copy behind the planes of n_sys systems (types.hpp, aos_pitch): system k's
+// planes start at tab + k * sys_elems, its copy kNumFields * p * stride doubles further.  HBM to HBM, so the upload
+// carries the planes only.
 #define STORM_DECL_COMMON(ns)                                                                                     \
   namespace ns {                                                                                                  \
   hipError_t launch_chain(const storm::SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps, \
@@ -23,6 +26,7 @@ inline size_t swap_blocks(size_t n) { return n < 2 ? 0 : (n - 1 + 1023) / 1024; 
                           const int* sys_index = nullptr);                                                        \
   hipError_t launch_chain_scaled(const storm::SystemDev& s, bool ell0, const double* freq, size_t n,               \
                                  const double* steps, double* mantissa_out, long long* exponent_out, hipStream_t stream); \
+  hipError_t launch_aos_copy(double* tab, size_t n_sys, size_t sys_elems, size_t stride, int p, hipStream_t stream); \
   hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count, int* flags, hipStream_t stream); \
   hipError_t launch_swap_emit(const double* freq, const double* det, size_t n, const unsigned* block_offset,       \
                               storm::BracketDev* out, unsigned long long* index_out, hipStream_t stream);          \

@@ -34,6 +34,41 @@ SDEV M4 interval_step(const SystemDev& s, size_t i, double f, const FreqTerms& u
   return interval_step_from<SCHEME, ELL0, UNIFORM>(c, s.lambda, f, ut, ok);
 }
 
+// The same from the interval-major copy of the coefficients (types.hpp, aos_pitch): one address per lane, 16-byte loads
+// at immediate offsets.  Same values, same bits.
+template <int SCHEME, bool ELL0, bool UNIFORM>
+SDEV M4 interval_step_aos(const SystemDev& s, size_t i, double f, const FreqTerms& ut, bool& ok) {
+  constexpr int kP = scheme_points(SCHEME);
+  const AosCoef<kP> c{static_cast<const double*>(
+      __builtin_assume_aligned(s.tab + kNumFields * s.plane + i * (size_t)aos_pitch(kP), 16))};
+  return interval_step_from<SCHEME, ELL0, UNIFORM>(c, s.lambda, f, ut, ok);
+}
+
+// Where the column-owner body takes its coefficients from the interval-major copy (AosCoef: 23 address instructions and
+// half the load instructions less per interval for Colloc4) instead of the planes.  Same values, same bits.  Measured on
+// one box, both trees alternating, 10^5 frequencies on tams (ms, planes -> copy): parity Colloc2 10.49 -> 10.28, Colloc4
+// 23.56 -> 22.92, Magnus2 24.47 -> 24.72, Magnus6 40.7 -> 40.6, Magnus8 73.1 -> 83.9 (!); FMA build Colloc2 5.58 -> 5.42,
+// Colloc4 10.71 -> 10.27, Magnus2 14.95 -> 14.73, Magnus6 25.57 -> 24.95, Magnus8 49.4 -> 45.8.
+__host__ __device__ constexpr bool col_reads_aos(int scheme) {
+#ifdef STORM_FAST_BUILD
+  return true;
+#else
+  return scheme == kColloc2 || scheme == kColloc4;
+#endif
+}
+
+// The 16/32-lane body of det_hex (without LDS prefetch; single solvers only -- for a sweep the second copy of every
+// system's planes costs more in allocation and upload than the kernels gain): same-box A/B at 12 288 and 49 152
+// frequencies, FMA build: Colloc4 1.65 -> 1.54 ms and 6.05 -> 5.73, Colloc2 -3 %, Magnus6 -3 / -5 %, Magnus8 -7 %, Magnus2
+// +-0; parity build: Colloc2 -4 %, Colloc4 +-0, Magnus2 +5 %, Magnus6 +2 %, Magnus8 +9 %.
+__host__ __device__ constexpr bool hex_reads_aos(int scheme) {
+#ifdef STORM_FAST_BUILD
+  return true;
+#else
+  return scheme == kColloc2;
+#endif
+}
+
 template <int SCHEME, bool ELL0, bool UNIFORM>
 __global__ __launch_bounds__(64) void det_fused_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                        double* __restrict__ det_out, int* __restrict__ flags) {
@@ -189,7 +224,8 @@ __host__ __device__ constexpr int hex_lds_doubles() {
 }
 
 // The work of workgroup `block` (one wave) of det_hex; `lds`: hex_lds_doubles<SCHEME, LPF>() doubles, 16-B aligned.
-template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
+// AOS: the system is a single solver's, which has the interval-major copy of the planes (a sweep's systems have not).
+template <int SCHEME, bool ELL0, bool UNIFORM, int LPF, bool AOS>
 SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, size_t n, double* __restrict__ det_out,
                        int* __restrict__ flags, const SystemDev* __restrict__ table, const int* __restrict__ sys_index,
                        size_t block, double* __restrict__ lds) {
@@ -235,7 +271,8 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
       buf ^= 1;
     } else {
       // rows are padded past n_int with copies of the last interval, so no clamping is needed
-      l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + sub, f, ut, ok);
+      if constexpr (AOS && hex_reads_aos(SCHEME)) l = interval_step_aos<SCHEME, ELL0, UNIFORM>(s, i0 + sub, f, ut, ok);
+      else l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + sub, f, ut, ok);
     }
     __syncthreads();  // previous round's rows have been consumed
 #pragma unroll
@@ -278,12 +315,12 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
   }
 }
 
-template <int SCHEME, bool ELL0, bool UNIFORM, int LPF>
+template <int SCHEME, bool ELL0, bool UNIFORM, int LPF, bool AOS = false>
 __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(SystemDev s0, const double* __restrict__ freq, size_t n,
                                                      double* __restrict__ det_out, int* __restrict__ flags,
                                                      const SystemDev* __restrict__ table, const int* __restrict__ sys_index) {
   __shared__ __attribute__((aligned(16))) double lds[hex_lds_doubles<SCHEME, LPF>()];
-  det_hex_body<SCHEME, ELL0, UNIFORM, LPF>(s0, freq, n, det_out, flags, table, sys_index, (size_t)blockIdx.x, lds);
+  det_hex_body<SCHEME, ELL0, UNIFORM, LPF, AOS>(s0, freq, n, det_out, flags, table, sys_index, (size_t)blockIdx.x, lds);
 }
 
 // Column-owner variant ("det_col"): 4 lanes per frequency, 16 frequencies per wave.  Phase A as in det_hex (lane q builds the
@@ -295,19 +332,6 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 // L*acc is evaluated term by term in the reference's gemm order, so the bits are the same.  It has a quarter of det_hex's
 // waves, each four times as long: the launcher uses it for whole wave rounds of large batches and sends the remainder
 // through det_hex (launch_hex in scheme_tu.hip).
-// Where the column-owner body takes its coefficients from the interval-major copy (AosCoef: 23 address instructions and
-// half the load instructions less per interval for Colloc4) instead of the planes.  Same values, same bits.  Measured on
-// one box, both trees alternating, 10^5 frequencies on tams (ms, planes -> copy): parity Colloc2 10.49 -> 10.28, Colloc4
-// 23.56 -> 22.92, Magnus2 24.47 -> 24.72, Magnus6 40.7 -> 40.6, Magnus8 73.1 -> 83.9 (!); FMA build Colloc2 5.58 -> 5.42,
-// Colloc4 10.71 -> 10.27, Magnus2 14.95 -> 14.73, Magnus6 25.57 -> 24.95, Magnus8 49.4 -> 45.8.
-__host__ __device__ constexpr bool col_reads_aos(int scheme) {
-#ifdef STORM_FAST_BUILD
-  return true;
-#else
-  return scheme == kColloc2 || scheme == kColloc4;
-#endif
-}
-
 constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
@@ -331,10 +355,7 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
     M4 l;
     if constexpr (col_reads_aos(SCHEME)) {
       // the coefficients come from the interval-major copy: one address per lane, 16-byte loads at immediate offsets
-      constexpr int kP = scheme_points(SCHEME);
-      const AosCoef<kP> cf{static_cast<const double*>(
-          __builtin_assume_aligned(s.tab + kNumFields * s.plane + (i0 + q) * (size_t)aos_pitch(kP), 16))};
-      l = interval_step_from<SCHEME, ELL0, UNIFORM>(cf, s.lambda, f, ut, ok);
+      l = interval_step_aos<SCHEME, ELL0, UNIFORM>(s, i0 + q, f, ut, ok);
     } else {
       l = interval_step<SCHEME, ELL0, UNIFORM>(s, i0 + q, f, ut, ok);
     }
@@ -404,7 +425,7 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_mix_kernel(Syst
   if (blockIdx.x < col_blocks)
     det_col_body<SCHEME, ELL0, UNIFORM>(s, freq, n_col, det_out, flags, (size_t)blockIdx.x, lds);
   else
-    det_hex_body<SCHEME, ELL0, UNIFORM, 16>(s, freq + n_col, n - n_col, det_out + n_col, flags, nullptr, nullptr,
+    det_hex_body<SCHEME, ELL0, UNIFORM, 16, true>(s, freq + n_col, n - n_col, det_out + n_col, flags, nullptr, nullptr,
                                             (size_t)(blockIdx.x - col_blocks), lds);
 }
 

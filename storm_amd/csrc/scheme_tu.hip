@@ -73,8 +73,13 @@ static hipError_t launch_hex_lpf(const LaunchArgs& a) {
     const size_t off = w0 * kFreqs;
     const size_t n = std::min(a.n - off, per_launch * kFreqs);
     const unsigned blocks = (unsigned)((n + kFreqs - 1) / kFreqs);
-    det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(
-        a.sys, a.freq + off, n, a.out + off, a.flags, a.table, a.sys_index ? a.sys_index + off : nullptr);
+    // a single solver's system has the interval-major copy of its planes, a sweep's systems have not
+    if (hex_reads_aos(STORM_SCHEME) && a.table == nullptr)
+      det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF, true><<<blocks, 64, 0, a.stream>>>(
+          a.sys, a.freq + off, n, a.out + off, a.flags, nullptr, nullptr);
+    else
+      det_hex_kernel<STORM_SCHEME, ELL0, UNIFORM, LPF><<<blocks, 64, 0, a.stream>>>(
+          a.sys, a.freq + off, n, a.out + off, a.flags, a.table, a.sys_index ? a.sys_index + off : nullptr);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

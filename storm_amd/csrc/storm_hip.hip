@@ -627,16 +627,8 @@ void build_planes(const storm_system_desc& d, double* t, bool& uniform, double& 
       }
 }
 
-// The interval-major copy behind the planes (types.hpp, aos_pitch): `t` holds planes_elems + aos_elems doubles.
+// The interval-major copy behind the planes (types.hpp, aos_pitch), filled on the device by launch_aos_copy.
 size_t aos_elems(size_t n_int, size_t p) { return padded_stride(n_int) * size_t(aos_pitch(int(p))); }
-void build_aos(size_t n_int, size_t p, double* t) {
-  const size_t stride = padded_stride(n_int), pitch = size_t(aos_pitch(int(p))), rows = size_t(kNumFields) * p;
-  double* aos = t + planes_elems(n_int, p);
-  for (size_t i = 0; i < stride; ++i) {
-    for (size_t r = 0; r < rows; ++r) aos[i * pitch + r] = t[r * stride + i];
-    for (size_t r = rows; r < pitch; ++r) aos[i * pitch + r] = 0.0;
-  }
-}
 
 void count_launch(storm_solver* s, uint64_t k = 1) { s->stats.launches += k; }
 
@@ -1269,10 +1261,9 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     hip_check(hipGetDevice(&s->device), "hipGetDevice");
     s->scheme = d->scheme;
     double rotm0 = 0.0;
-    const size_t tab_elems = planes_elems(d->n_int, d->p) + aos_elems(d->n_int, d->p);
-    s->h_vec.reserve(tab_elems);  // built in the (cached) pinned block the upload is staged from
+    const size_t soa_elems = planes_elems(d->n_int, d->p), tab_elems = soa_elems + aos_elems(d->n_int, d->p);
+    s->h_vec.reserve(soa_elems);  // built in the (cached) pinned block the upload is staged from
     build_planes(*d, s->h_vec.p, s->uniform, rotm0);
-    build_aos(d->n_int, d->p, s->h_vec.p);
     const double ell = double(d->ell);
     s->ell0 = (ell == 0.0);
     if (s->ell0) s->uniform = true;  // rotation does not enter for ell == 0
@@ -1284,8 +1275,9 @@ int storm_solver_create(const storm_system_desc* d, storm_solver** out) {
     // create could otherwise read the planes before the DMA has landed.
     // (staged through a cached pinned buffer: a copy from pageable memory goes through the runtime's own staging
     // path, which serialises concurrent creates)
-    hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, tab_elems * sizeof(double), hipMemcpyHostToDevice, s->stream),
+    hip_check(hipMemcpyAsync(s->tab.p, s->h_vec.p, soa_elems * sizeof(double), hipMemcpyHostToDevice, s->stream),
               "planes H2D");
+    hip_check(storm::launch_aos_copy(s->tab.p, 1, tab_elems, padded_stride(d->n_int), int(d->p), s->stream), "aos copy launch");
     s->d_flags.reserve(2);  // [0]: calls on the library stream (read back and reset by check_flags), [1]: caller streams
     hip_check(hipMemsetAsync(s->d_flags.p, 0, 2 * sizeof(int), s->stream), "flags memset");
     hip_check(hipEventCreateWithFlags(&s->ready, hipEventDisableTiming), "hipEventCreate");
@@ -2585,7 +2577,7 @@ int storm_sweep_create(const storm_system_desc* descs, size_t n_sys, storm_sweep
     q = new storm_sweep();
     hip_check(hipGetDevice(&q->device), "hipGetDevice");
     q->scheme = d0.scheme; q->n_sys = n_sys; q->n_int = d0.n_int; q->p = d0.p;
-    const size_t elems = planes_elems(q->n_int, q->p);
+    const size_t elems = planes_elems(q->n_int, q->p);  // (no interval-major copy: see DESIGN.md section 12)
     // The kernel class of a system (ell == 0 / bitwise-uniform m*rot / general) decides its internal position; it follows
     // from the descriptor alone (same test as build_planes).
     std::vector<char> uniform(n_sys, 1);
