@@ -175,6 +175,25 @@ SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
   return t;
 }
 
+// FMA build, 16 lanes per frequency: phase B as ONE v_mfma_f64_4x4x4 per interval and wave (four independent 4x4x4
+// products per instruction = the wave's four frequencies) instead of 4 multiply-adds + 8 DPP moves + two 16-byte LDS
+// reads per lane.  Operand layout measured with tools/mfma64_microbench.hip: block b = lanes {4b + q + 16 r};
+// A[i][k] in lane 4b + i + 16k, B[k][j] in lane 4b + j + 16k, D[i][j] in lane 4b + j + 16i -- D's layout is B's, so the
+// running product P <- S P chains from D into B with no shuffle (12 ns per dependent step; the DPP/FMA step: 56 ns).
+// FP64 MFMA runs through the same FP64 pipe as v_fma_f64 on gfx950 (the microbench: VALU + MFMA together never pass
+// 78 TFLOP/s), so this buys issue slots and LDS traffic (8 B instead of 32 B per lane and interval), not flops.  The
+// sum over k is fused in the hardware's order: not offered in the parity build.
+// Same-box A/B against the multiply-add phase B (tams, FMA build, 12 288 / 10^5 frequencies, 16 lanes forced): Colloc4
+// -9 / -8 %, Colloc8 -5 / -6 %, Magnus2 -8 / -5 %, Magnus8 0 / -4 %; Colloc2 -1 / +4 %, Colloc6 +1 / +1 %, Magnus6 0 / +1 %:
+// those three keep the multiply-adds in det_hex (the column-owner body gains with every scheme, kColMfma below).
+__host__ __device__ constexpr bool hex_uses_mfma(int scheme, int lpf) {
+#ifdef STORM_FAST_BUILD
+  return (lpf == 16 || lpf == 32) && scheme != kColloc2 && scheme != kColloc6 && scheme != kMagnus6;
+#else
+  return false;
+#endif
+}
+
 // Magnus 2/4/6 need just over 256 registers when left alone; capping them at 256 buys a second wave
 // per SIMD (better issue utilisation, phase-B latency hidden behind the other wave's phase A).
 __host__ __device__ constexpr int hex_min_waves(int scheme) {
@@ -240,9 +259,13 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
   constexpr int kHandOff = (kFreqs * kGroup + 1) / 2 * 2;  // doubles, keeps the tiles 16-B aligned
   double* const coef = lds + kHandOff;
   const int tid = threadIdx.x;
-  const int g = tid / LPF;    // frequency within the wave
-  const int sub = tid % LPF;  // interval within the round (phase A)
-  const int e = tid & 15;     // element c*4+r of the product (phase B)
+  constexpr bool kMfma = hex_uses_mfma(SCHEME, LPF);
+  // (MFMA phase B: MFMA block b = lanes {4b + q + 16 r}.  16 lanes per frequency: block b is frequency b.  32 lanes: blocks
+  // 2g and 2g + 1 both carry the product of frequency g, as the two 16-lane halves of a group do in the multiply-add form.)
+  static_assert(!kMfma || LPF == 16 || LPF == 32, "MFMA phase B: 16 or 32 lanes per frequency");
+  const int g = kMfma ? (LPF == 16 ? (tid >> 2) & 3 : (tid >> 3) & 1) : tid / LPF;  // frequency within the wave
+  const int sub = kMfma ? (tid & 3) + 4 * (tid >> 4) + (LPF == 32 ? 4 * (tid & 4) : 0) : tid % LPF;  // interval within the round (phase A)
+  const int e = kMfma ? (tid & 3) * 4 + (tid >> 4) : tid & 15;      // element c*4+r of the product (phase B)
   const int r = e & 3;
   const int c = e >> 2;
   const size_t t = block * kFreqs + g;
@@ -254,7 +277,8 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
   double acc = (r == c) ? 1.0 : 0.0;
   const size_t n_int = s.n_int;
   double* __restrict__ mine = lds + g * kGroup + sub * kHexLaneStride;
-  const double* __restrict__ rows = lds + g * kGroup + r * 4;
+  // (MFMA: this lane's A operand is S(i, k) with i = tid % 4, k = tid / 16, row-major in the hand-off)
+  const double* __restrict__ rows = kMfma ? lds + g * kGroup + (tid & 3) * 4 + (tid >> 4) : lds + g * kGroup + r * 4;
   if constexpr (kPrefetch) {
     if (n_int > 0) hex_stage_coefficients<SCHEME, LPF>(s, 0, coef, tid);
   }
@@ -281,6 +305,22 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
       *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
     }
     __syncthreads();
+    if constexpr (kMfma) {
+#pragma unroll
+      for (int h = 0; h < LPF; h += 16) {
+        double av[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) av[k] = rows[(h + k) * kHexLaneStride];
+        if (i0 + h + 16 <= n_int) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av[k], acc, 0.0, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (i0 + h + k < n_int) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av[k], acc, 0.0, 0, 0, 0);
+        }
+      }
+    } else
 #pragma unroll
     for (int h = 0; h < LPF; h += 16) {
       double2 lo[16], hi[16];
@@ -300,7 +340,7 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
     }
   }
   __syncthreads();
-  if (sub < 16) lds[g * kGroup + e] = acc;  // column-major element c*4+r
+  if (kMfma ? sub < 16 || LPF == 16 : sub < 16) lds[g * kGroup + e] = acc;  // column-major element c*4+r
   const unsigned long long bad = __ballot(!ok);
   __syncthreads();
   if (sub == 0 && t < n) {
@@ -308,7 +348,9 @@ SDEV void det_hex_body(const SystemDev& s0, const double* __restrict__ freq, siz
 #pragma unroll
     for (int k = 0; k < 16; ++k) a.v[k] = lds[g * kGroup + k];
     constexpr unsigned long long kMask = LPF == 64 ? ~0ULL : ((1ULL << (LPF & 63)) - 1ULL);
-    const bool group_ok = ((bad >> (g * LPF)) & kMask) == 0;
+    const bool group_ok = !kMfma      ? ((bad >> (g * LPF)) & kMask) == 0
+                          : LPF == 16 ? ((bad >> (4 * g)) & 0x000F000F000F000FULL) == 0
+                                      : ((bad >> (8 * g)) & 0x00FF00FF00FF00FFULL) == 0;
     const double det = close_determinant<ELL0>(s, f, a);
     det_out[t] = group_ok ? det : __longlong_as_double(0x7ff8000000000000LL);
     if (!group_ok) atomicOr(flags, 1);
@@ -332,7 +374,18 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 // L*acc is evaluated term by term in the reference's gemm order, so the bits are the same.  It has a quarter of det_hex's
 // waves, each four times as long: the launcher uses it for whole wave rounds of large batches and sends the remainder
 // through det_hex (launch_hex in scheme_tu.hip).
+#ifdef STORM_FAST_BUILD
+// FMA build: phase B through v_mfma_f64_4x4x4 as in det_hex (hex_uses_mfma above): MFMA (Q, k) applies the step matrices of
+// interval slot k to the products of frequencies 4Q .. 4Q+3, one product per MFMA block, so a round is four independent
+// chains of four dependent MFMAs (det_hex: one chain of sixteen) and 16 MFMAs + 16 eight-byte LDS reads per lane instead
+// of 64 multiply-adds + 32 sixteen-byte reads.  640 B per frequency: the four blocks of an MFMA read four different
+// 128-B bank windows.
+constexpr bool kColMfma = true;
+constexpr int kColGroup = 4 * kHexLaneStride + 8;
+#else
+constexpr bool kColMfma = false;
 constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
+#endif
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
 SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size_t n, double* __restrict__ det_out,
@@ -344,12 +397,16 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
   const double f = freq[t < n ? t : n - 1];
   const FreqTerms ut = freq_terms<ELL0>(f, s.rotm_uniform, s.lambda);
   bool ok = true;
+  // VALU phase B: column q of this frequency's product.  MFMA phase B: element (row tid / 16, column tid % 4) of the
+  // products of frequencies 4Q + (tid / 4) % 4, Q = 0..3 (the D/B operand layout, hex_uses_mfma above).
   double col[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) col[r] = (r == q) ? 1.0 : 0.0;
+  for (int r = 0; r < 4; ++r) col[r] = kColMfma ? (((tid >> 4) == q) ? 1.0 : 0.0) : ((r == q) ? 1.0 : 0.0);
   const size_t n_int = s.n_int;
   double* __restrict__ mine = lds + g * kColGroup + q * kHexLaneStride;
-  const double* __restrict__ mats = lds + g * kColGroup;
+  [[maybe_unused]] const double* __restrict__ mats = lds + g * kColGroup;
+  // MFMA A operand: S(i, k) with i = tid % 4, k = tid / 16 of frequency 4Q + (tid / 4) % 4, row-major in the hand-off
+  [[maybe_unused]] const double* __restrict__ aop = lds + ((tid >> 2) & 3) * kColGroup + q * 4 + (tid >> 4);
   for (size_t i0 = 0; i0 < n_int; i0 += 4) {
     // rows are padded past n_int with copies of the last interval, so no clamping is needed
     M4 l;
@@ -366,6 +423,21 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
       *reinterpret_cast<double2*>(mine + rr * 4 + 2) = make_double2(l.v[2 * 4 + rr], l.v[3 * 4 + rr]);
     }
     __syncthreads();
+    if constexpr (kColMfma) {
+      double av[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) av[k][qq] = aop[qq * 4 * kColGroup + k * kHexLaneStride];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n_int) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) col[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[k][qq], col[qq], 0.0, 0, 0, 0);
+        }
+      }
+      continue;
+    }
     double2 m[4][8];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -390,7 +462,10 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lds[g * kColGroup + q * 4 + r] = col[r];  // column-major element q*4+r
+  for (int r = 0; r < 4; ++r) {  // column-major element c*4+r
+    if constexpr (kColMfma) lds[(r * 4 + ((tid >> 2) & 3)) * kColGroup + q * 4 + (tid >> 4)] = col[r];
+    else lds[g * kColGroup + q * 4 + r] = col[r];
+  }
   const unsigned long long bad = __ballot(!ok);
   __syncthreads();
   if (q == 0 && t < n) {

@@ -52,7 +52,9 @@ template <bool ELL0, bool UNIFORM, int LPF>
 static double hex_cost(size_t n, size_t n_int) {
   constexpr double kStepFlops[8] = {610., 1396., 2694., 5048., 1486., 1848., 2562., 3900.};
   const size_t waves = (n * LPF + 63) / 64, slots = hex_wave_slots<ELL0, UNIFORM, LPF>();
-  return double((waves + slots - 1) / slots) * double((n_int + LPF - 1) / LPF) * (kStepFlops[STORM_SCHEME] + 20.0 * LPF);
+  // (an MFMA step of the ordered product, FMA build: one 16-cycle instruction per wave and an 8-byte LDS read per lane)
+  const double step_cost = hex_uses_mfma(STORM_SCHEME, LPF) ? 8.0 : 20.0;
+  return double((waves + slots - 1) / slots) * double((n_int + LPF - 1) / LPF) * (kStepFlops[STORM_SCHEME] + step_cost * LPF);
 }
 // A batch of more waves than the GPU holds goes out in pieces of whole wave rounds.  All waves of a piece end together
 // (equal work), and between two pieces the dispatcher serves the other streams: with ONE launch of several rounds it

@@ -155,7 +155,14 @@ def test_sweep_equals_separate_handles_and_fast_mode(oracle, golden_dir):
             sweep.set_option("hex_lanes", lanes)
             again = sweep.det(grids)
             for k in range(len(cfg)):
-                assert same_bits(again[k], got[k][1]), (arith, lanes, k)
+                if arith:
+                    # FMA build: the 16-lane kernel sums the ordered product in v_mfma_f64_4x4x4 (fused, the hardware's
+                    # order), the 32-lane kernel in v_fma_f64: the fast build's tolerance contract, not the same bits
+                    scale = np.max(np.abs(got[k][1]))
+                    assert np.max(np.abs(again[k] - got[k][1])) <= 1e-9 * scale, (arith, lanes, k)
+                    assert np.array_equal(np.signbit(again[k]), np.signbit(got[k][1])), (arith, lanes, k)
+                else:
+                    assert same_bits(again[k], got[k][1]), (arith, lanes, k)
 
 
 def test_sweep_modes_through_host_mirror(oracle, golden_dir):
