@@ -45,13 +45,14 @@ FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "collo
 # summaries are under profiles/), keyed by (kernel, frequencies, arithmetic).  FETCH_SIZE (reported in KB) is doubled as
 # MI355X_MICROARCH.md prescribes for gfx950 -- a correction calibrated on 16-byte loads; these kernels read the coefficient
 # planes with 8-byte loads, so the figure is an upper bound.  The algorithmic bytes are ~2.7 MB (planes once + 16 B per
-# frequency); the surplus is one fetch of the planes per XCD L2 and, in the FMA build, 20 B/lane of register spills.
+# frequency); the surplus is one fetch of the planes and of their interval-major copy per XCD L2 and, in the FMA build,
+# 36 B/lane of register spills.
 TRAFFIC = {("det_hex<colloc8>", 10000, 0): 2 * 10872.8e3 + 156.25e3,          # profiles/r01_pmc_det_hex_colloc8.txt
-           ("det_hex<colloc4>", 100000, 1): 2 * 9874.52e3 + 7450.92e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
-           ("det_hex<colloc4>", 100000, 0): 2 * 8445.35e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
+           ("det_hex<colloc4>", 100000, 1): 2 * 11621.1e3 + 11981.2e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
+           ("det_hex<colloc4>", 100000, 0): 2 * 16873.3e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
 # Flops the FMA build EXECUTES per evaluation (FMA = 2), counted in the ISA of its dominant loop: since the stage system is
 # solved by LU and the scalings are folded it does less arithmetic than the reference's formulation.
-EXECUTED_FLOPS_FAST = {"colloc4": 754.0}                                       # profiles/r02_isa_det_mix_colloc4_fast.txt
+EXECUTED_FLOPS_FAST = {"colloc4": 770.0}                                       # profiles/r02_isa_det_mix_colloc4_fast.txt
 PEAK_FP64_TFLOPS = 78.6     # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz) = the dense FP64 MFMA peak
 UNFUSED_TFLOPS = 38.1       # measured chip-wide ceiling of separate v_mul_f64 / v_add_f64 (tools/fp64_microbench.hip)
 HBM_PEAK_GBS = 8000.0
@@ -220,7 +221,9 @@ def main():
             1: "same kernel built with FMA contraction (option arithmetic=1). `achieved` keeps the reference formulation's "
                "un-fused count (1396.1 flops per evaluation), so it is comparable between the two builds and between rounds "
                "-- and can pass the peak, because this build re-formulates the step (LU stage solve, folded scalings, "
-               "re-associated inverse: DESIGN.md section 5) and executes 754 flops per evaluation; `executed` is the "
+               "re-associated inverse: DESIGN.md section 5) and executes 770 flops per evaluation, 128 of them the ordered product "
+               "as v_mfma_f64_4x4x4 (four frequencies per instruction; FP64 MFMA shares the vector FP64 pipe and its peak on "
+               "gfx950: tools/mfma64_microbench.hip); `executed` is the "
                "hardware's own rate (flops counted in the ISA, profiles/r02_isa_det_mix_colloc4_fast.txt)"}
 
     def roofline_of(arith):
@@ -240,7 +243,11 @@ def main():
         flops_per_launch = len(mine) * n_int * FLOPS_PER_EVAL["colloc4"] * reps / cnt
         achieved = flops_per_launch / (ms / cnt * 1e-3) / 1e12
         kernel = f"{kind}<colloc4>"
-        r = {"bound": "compute", "pipe": "fp64-valu (no MFMA: 4x4 products in a strict order, DESIGN.md section 2)",
+        pipe = ("fp64-valu (no MFMA: 4x4 products in the reference's order with separate mul and add, DESIGN.md section 2)"
+                if arith == 0 else
+                "fp64-valu + fp64-mfma, one pipe and one peak on gfx950 (the step matrices in v_fma_f64, the ordered "
+                "product in v_mfma_f64_4x4x4: DESIGN.md section 5)")
+        r = {"bound": "compute", "pipe": pipe,
              "kernel": kernel, "achieved": round(achieved, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
              "frac": round(achieved / PEAK_FP64_TFLOPS, 4), "traffic": TRAFFIC.get((kernel, len(mine), arith)),
              "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "flops_per_launch": flops_per_launch,

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(64) void det_quad_kernel(SystemDev s, const double*
 // picks the LPF whose wave count packs the chip's wave slots best (see launch_hex in scheme_tu.hip).
 constexpr int kHexLaneStride = 18;  // doubles; 16 + 2 of padding (LDS banks)
 __host__ __device__ constexpr int hex_group_stride(int lpf) { return lpf * kHexLaneStride + 4; }  // doubles
+// (Measured with the MFMA phase B: a group stride of 128 B past a multiple of 512 B, which gives the four blocks of an
+// MFMA four different bank windows for their operand reads, changes nothing -- +-0.5 %, Magnus8 +5 % at 12 288
+// frequencies: the LDS is not what these kernels wait for.)
 
 SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
   const double a0 = quad_bcast_d<0>(acc), a1 = quad_bcast_d<1>(acc), a2 = quad_bcast_d<2>(acc), a3 = quad_bcast_d<3>(acc);
@@ -185,7 +188,7 @@ SDEV double hex_chain_step(double acc, double2 lo, double2 hi) {
 // sum over k is fused in the hardware's order: not offered in the parity build.
 // Same-box A/B against the multiply-add phase B (tams, FMA build, 12 288 / 10^5 frequencies, 16 lanes forced): Colloc4
 // -9 / -8 %, Colloc8 -5 / -6 %, Magnus2 -8 / -5 %, Magnus8 0 / -4 %; Colloc2 -1 / +4 %, Colloc6 +1 / +1 %, Magnus6 0 / +1 %:
-// those three keep the multiply-adds in det_hex (the column-owner body gains with every scheme, kColMfma below).
+// those three keep the multiply-adds in det_hex (the column-owner body: col_uses_mfma below).
 __host__ __device__ constexpr bool hex_uses_mfma(int scheme, int lpf) {
 #ifdef STORM_FAST_BUILD
   return (lpf == 16 || lpf == 32) && scheme != kColloc2 && scheme != kColloc6 && scheme != kMagnus6;
@@ -374,22 +377,28 @@ __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_hex_kernel(Syst
 // L*acc is evaluated term by term in the reference's gemm order, so the bits are the same.  It has a quarter of det_hex's
 // waves, each four times as long: the launcher uses it for whole wave rounds of large batches and sends the remainder
 // through det_hex (launch_hex in scheme_tu.hip).
-#ifdef STORM_FAST_BUILD
 // FMA build: phase B through v_mfma_f64_4x4x4 as in det_hex (hex_uses_mfma above): MFMA (Q, k) applies the step matrices of
 // interval slot k to the products of frequencies 4Q .. 4Q+3, one product per MFMA block, so a round is four independent
 // chains of four dependent MFMAs (det_hex: one chain of sixteen) and 16 MFMAs + 16 eight-byte LDS reads per lane instead
 // of 64 multiply-adds + 32 sixteen-byte reads.  640 B per frequency: the four blocks of an MFMA read four different
-// 128-B bank windows.
-constexpr bool kColMfma = true;
-constexpr int kColGroup = 4 * kHexLaneStride + 8;
+// 128-B bank windows.  Same-box A/B against the multiply-add form (column owners alone, 12 288 / 10^5 frequencies): Colloc4
+// -7 / -6 %, Colloc6 -4 / -2 %, Magnus2 -5 / -4 %, Magnus6 -1 / -3 %, Magnus8 -2 / -1 %; not Colloc2, whose det_mix came out
+// 5 % slower at 10^5 frequencies with it.
+__host__ __device__ constexpr bool col_uses_mfma(int scheme) {
+#ifdef STORM_FAST_BUILD
+  return scheme != kColloc2;
 #else
-constexpr bool kColMfma = false;
-constexpr int kColGroup = 4 * kHexLaneStride + 2;  // doubles per frequency: four matrices of 18 (+2: bank spread)
+  return false;
 #endif
+}
+// doubles per frequency: four matrices of 18 (+2: bank spread; MFMA: +8)
+__host__ __device__ constexpr int col_group_stride(int scheme) { return 4 * kHexLaneStride + (col_uses_mfma(scheme) ? 8 : 2); }
 
 template <int SCHEME, bool ELL0, bool UNIFORM>
 SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size_t n, double* __restrict__ det_out,
                        int* __restrict__ flags, size_t block, double* __restrict__ lds) {
+  constexpr bool kColMfma = col_uses_mfma(SCHEME);
+  constexpr int kColGroup = col_group_stride(SCHEME);
   const int tid = threadIdx.x;
   const int g = tid >> 2;  // frequency within the wave
   const int q = tid & 3;   // interval within the round (phase A), column of the product (phase B)
@@ -429,11 +438,18 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) av[k][qq] = aop[qq * 4 * kColGroup + k * kHexLaneStride];
+      if (i0 + 4 <= n_int) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (i0 + k < n_int) {
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) col[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[k][qq], col[qq], 0.0, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (i0 + k < n_int) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) col[qq] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[k][qq], col[qq], 0.0, 0, 0, 0);
+          }
         }
       }
       continue;
@@ -482,7 +498,7 @@ SDEV void det_col_body(const SystemDev& s, const double* __restrict__ freq, size
 template <int SCHEME, bool ELL0, bool UNIFORM>
 __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_col_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                                            double* __restrict__ det_out, int* __restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) double lds[16 * kColGroup];
+  __shared__ __attribute__((aligned(16))) double lds[16 * col_group_stride(SCHEME)];
   det_col_body<SCHEME, ELL0, UNIFORM>(s, freq, n, det_out, flags, (size_t)blockIdx.x, lds);
 }
 
@@ -494,7 +510,7 @@ template <int SCHEME, bool ELL0, bool UNIFORM>
 __global__ __launch_bounds__(64, hex_min_waves(SCHEME)) void det_mix_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                                            double* __restrict__ det_out, int* __restrict__ flags,
                                                                            unsigned col_blocks) {
-  constexpr int kLds = hex_lds_doubles<SCHEME, 16>() > 16 * kColGroup ? hex_lds_doubles<SCHEME, 16>() : 16 * kColGroup;
+  constexpr int kLds = hex_lds_doubles<SCHEME, 16>() > 16 * col_group_stride(SCHEME) ? hex_lds_doubles<SCHEME, 16>() : 16 * col_group_stride(SCHEME);
   __shared__ __attribute__((aligned(16))) double lds[kLds];
   const size_t n_col = (size_t)col_blocks * 16;  // (the launcher keeps n_col <= n)
   if (blockIdx.x < col_blocks)
