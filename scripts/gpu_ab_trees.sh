@@ -11,7 +11,7 @@ for rep in $(seq $REPS); do
   for tree in tmp_old .; do
     echo "== tree $tree rep $rep" >> $O/ab_trees.txt
     for n in $NS; do for l in $LANES; do
-      (cd $R/$tree && timeout -k 10 300 python scripts/time_scheme.py $SCHEMES $n $l 2>&1 | grep "arith=1") >> $O/ab_trees.txt || exit 1
+      (cd $R/$tree && timeout -k 10 300 python scripts/time_scheme.py $SCHEMES $n $l 2>&1 | grep "arith=") >> $O/ab_trees.txt || exit 1
     done; done
   done
 done
