@@ -80,3 +80,24 @@ def test_scan_roots_and_brackets_through_the_mfma_bodies(oracle, oracle_models):
         assert [b["index"] for b in got] == [b["index"] for b in want], lanes
         gr, wr = np.array([b["root"] for b in got]), np.array([b["root"] for b in want])
         assert np.all(np.abs(gr - wr) <= 1e-10 * np.abs(wr)), (lanes, np.max(np.abs(gr - wr) / np.abs(wr)))
+
+
+@pytest.mark.parametrize("scheme", ["colloc4", "magnus2", "magnus8"])
+def test_tiny_and_ragged_grids(oracle, oracle_models, scheme):
+    """Grids of 1 .. 49 intervals (a stretch of the zams grid): fewer intervals than one round holds, exactly one round,
+    one more than a round -- every guard of the conditional MFMA chain -- for each body, against the oracle."""
+    model = oracle_models("zams")
+    full = model.field("r_coord")
+    f = oracle.linspace(1.5, 12.0, 531)
+    for npts in (2, 4, 5, 6, 16, 17, 18, 33, 34, 50):
+        o = oracle.Solver(model, 2, 0, scheme, np.ascontiguousarray(full[800:800 + npts]))
+        assert o.n_int == npts - 1
+        ref = o.det(f, threads=16)
+        assert np.all(np.isfinite(ref)), npts
+        scale = local_scale(ref)
+        h = fast_solver(o)
+        for lanes in (16, 32, 4, -80):
+            h.set_option("hex_lanes", lanes)
+            got = h.det(f)
+            assert np.all(np.abs(got - ref) <= DET_TOL * scale), (npts, lanes, np.max(np.abs(got - ref) / scale))
+            assert np.array_equal(np.signbit(got), np.signbit(ref)), (npts, lanes)
