@@ -468,16 +468,22 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
         on_grid = model.eval(grid)
         raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
         cp = {"modes": M, "n_pts": int(grid.size), "flops_per_pair_and_point": 148,
-              "kernel": "coupling_kernel<16> (+ its two prepasses: HIP events around the three launches)"}
+              "kernel": "coupling_kernel<16> (+ its two prepasses; in the FMA build + coupling_matrix_kernel, the tiles of like "
+                        "degrees on v_mfma_f64_16x16x4: HIP events around all launches)"}
         for arith in (0, 1):
             raw.set_option("arithmetic", arith)
             raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
             raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
             k_ms = raw.last_kernel_ms()
             ach = M * M * (grid.size - 1) * 148.0 / (k_ms * 1e-3) / 1e12
-            cp["fast" if arith else "parity"] = {"bound": "compute", "pipe": "fp64-valu", "avg_launch_ms": round(k_ms, 3),
+            cp["fast" if arith else "parity"] = {"bound": "compute", "pipe": "fp64-valu + fp64-mfma (one pipe)" if arith else "fp64-valu",
+                                                 "avg_launch_ms": round(k_ms, 3),
                                                  "achieved": round(ach, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                                                  "frac": round(ach / PEAK_FP64_TFLOPS, 4)}
+        cp["note"] = ("achieved = the reference formulation's 148 flops per (pair, point) / time, as for the discriminant kernels; the "
+                      "FMA build's matrix walk executes 21 v_mfma_f64_16x16x4 per four points and tile = 42 flops per (pair, point) "
+                      "plus the weighted left operands, and is bound by staging the fields from L2 / HBM (16 x 16 tiles: 5 bytes per "
+                      "(pair, point)), not by the pipe: DESIGN.md section 10")
         legs["coupling_integrals"] = cp
         del raw, c_fl, got
     del views, solvers

@@ -80,6 +80,250 @@ PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t
 // weights: uniform address, constant address space -> scalar loads
 typedef const double __attribute__((address_space(4))) * cp_const_ptr;
 
+#ifdef STORM_FAST_BUILD
+// Which 16 x 16 tiles the matrix-pipe walk takes (FMA build): full tiles whose 16 left modes share one degree and whose 16
+// right modes share one; of those with all ten factors zero (degrees more than 2 apart) only the ones whose 32 modes are
+// tame (see coupling_body) -- `null_walk` -- the others stay with the vector walk's full expression.  Wave-uniform, and
+// the same for every wave of a workgroup and for both kernels (every wave looks at the same 32 modes).
+struct CpMatrixTile { bool take, null_walk; };
+PDEV CpMatrixTile cp_matrix_tile(const CouplingArgs& a, size_t l0, size_t r0, int lane) {
+  const size_t M = a.n_modes;
+  if (!(l0 + 16 <= M && r0 + 16 <= M)) return CpMatrixTile{false, false};
+  const int mi = lane & 15;
+  const size_t lmi = l0 + mi, rmi = r0 + mi;
+  if (!__all(a.ell_index[lmi] == a.ell_index[l0] && a.ell_index[rmi] == a.ell_index[r0])) return CpMatrixTile{false, false};
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[l0] * a.n_ell + a.ell_index[r0]) * kCouplingConsts;
+  bool all_zero = true;
+#pragma unroll
+  for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && q[k] == 0.0;
+  if (!all_zero) return CpMatrixTile{true, false};
+  const bool tame = a.tame != nullptr && a.weights_tame && __all(a.tame[lmi] != 0 && a.tame[rmi] != 0);
+  return CpMatrixTile{tame, tame};
+}
+
+constexpr int kCpRing = 4;  // chunks staged at once in the matrix-pipe walk (kCpRing - 1 requested ahead)
+
+PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
+  constexpr int TILE = 16, kCpTile = 16, kCpPlane = CpGeom<16>::kPlane, kCpBufs = kCpRing;
+  constexpr int kCpTileDoubles = CpGeom<16>::kFieldTile + kCpChunk * kCouplingWeights;  // fields, then the points' weights
+  __shared__ __attribute__((aligned(16))) double tiles[kCpBufs][kCpTileDoubles];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const size_t M = a.n_modes, np = a.n_pts;
+  const size_t l0 = (size_t)tile_l * kCpTile, r0 = (size_t)tile_r * kCpTile;
+  const CpMatrixTile which = cp_matrix_tile(a, l0, r0, lane);
+  if (!which.take) return;
+  const bool null_walk = which.null_walk;
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[l0] * a.n_ell + a.ell_index[r0]) * kCouplingConsts;
+  const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
+  const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
+  const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
+  const double k6 = ipr + 6.0 * q2;
+  const int mi = lane & 15;
+  // ---- Matrix-pipe walk (FMA build, tiles whose 16 left modes share one degree and whose 16 right modes share one) ----
+  // With the ten factors constant over the tile every integrand is  sum_p (w_p(point) * left field_p) * right field:
+  // grouped by RIGHT field, an output is one v_mfma_f64_16x16x4 per right field it involves (K = four grid points):
+  //   d_squared, d_linear, d_zero: xi_r, xi_h            (3 x 2)
+  //   r_linear, r_zero:            xi_r, xi_h, xi_t+, xi_t-  (2 x 4)
+  //   l_zero = lz0 + F lz1 + F^2 lz2 (F = the right mode's frequency, a column scaling applied at the end):
+  //            lz0: xi_r, xi_h, rho';  lz1, lz2: xi_r, xi_h   (3 + 2 + 2)
+  // = 21 instructions per four points and tile, against ~60 vector instructions per (pair, point) of the walk below.
+  // Operand layout (tools/_probe, measured): A[i][k] in lane i + 16k, B[k][j] in lane j + 16k, D[i][j] in lane
+  // j + 16 (i % 4), element i / 4 -- lane = (mode, point) builds its own weighted left operand from the weights of ITS
+  // point.  A chunk of 8 staged points = two groups of four: wave w takes group w & 1 and output half w >> 1 (0: d_*,
+  // lz1, lz2; 1: r_*, lz0); the partial sums of the two groups meet in LDS at the end.  Same integrands, another
+  // association of the sum over the grid: the FMA build's tolerance (tests/test_hip_coupling.py).
+  // Degrees more than 2 apart (all ten factors zero, `null_walk`): what is left of l_zero is two instructions per four
+  // points (rho' and xi_r) on four of the nine planes.
+  {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int grp = wave & 1, half = wave >> 1, kpt = lane >> 4;
+    v4d acc[5];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) acc[o] = v4d{0.0, 0.0, 0.0, 0.0};
+    const double q2x2 = 2.0 * q2, q2hx2 = 2.0 * q2_h, k6x2 = 2.0 * k6;
+    // the weights of a chunk's points (160 B each, consecutive in memory) ride along with the fields: 1280 B = five
+    // LDS-DMA instructions of 256 B, issued by wave 0..3 and wave 0 again; every lane needs the weights of ITS point,
+    // so the scalar loads of the vector walk (one wave-uniform point at a time) do not fit here
+    auto stage_weights = [&](size_t rc0, double* tile) {
+#pragma unroll
+      for (int h = 0; h < 5; ++h) {
+        if ((h & 3) != wave) continue;  // wave-uniform
+        const int word = h * 64 + lane;                       // 4-byte word of the chunk's 8 x 40 words
+        size_t pt = rc0 + (size_t)(word / (2 * kCouplingWeights));
+        pt = pt < np ? pt : np - 1;
+        const char* src = reinterpret_cast<const char*>(a.weights + pt * kCouplingWeights) + (word % (2 * kCouplingWeights)) * 4;
+        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + CpGeom<TILE>::kFieldTile + h * 32), 4, 0, 0);
+      }
+    };
+    // A ring of kCpBufs staged chunks, kCpBufs - 1 of them requested ahead: a chunk of this walk is ~500 cycles of work
+    // per wave, less than one trip to L2, so one chunk of lookahead (enough for the vector walk) leaves every chunk
+    // waiting for its data.  Every chunk is requested -- past the grid's end as clamped copies of the last point, which
+    // `valid` keeps out of the sums -- so the count of requests in flight is the same constant at every wait.
+    constexpr int kAhead = kCpBufs - 1;
+    const size_t n_chunks = (np - 1 + kCpChunk - 1) / kCpChunk;
+    // Field staging of this walk: LDS image [plane][mode][point], one DMA instruction = 4 modes x 8 points, 16
+    // consecutive lanes on the 64 consecutive bytes of one mode's chunk (the vector walk's image is [point][mode]: 2
+    // points x 16 modes per instruction, i.e. 16 cache lines touched for 256 bytes -- at this walk's pace the address
+    // path of those requests was the bound: 14 ms at M = 1024 of one degree whatever the lookahead).  Wave w stages
+    // modes 4w .. 4w+3 of every plane.
+    const size_t lrow_m = a.rows ? (size_t)a.rows[l0 + 4 * wave + (lane >> 4)] : l0 + 4 * wave + (lane >> 4);
+    const size_t rrow_m = a.rows ? (size_t)a.rows[r0 + 4 * wave + (lane >> 4)] : r0 + 4 * wave + (lane >> 4);
+    auto stage_fields = [&](size_t rc0, double* tile) {
+      constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
+      size_t pt = rc0 + (size_t)((lane & 15) >> 1);
+      pt = pt < np ? pt : np - 1;
+#pragma unroll
+      for (int pl = 0; pl < 9; ++pl) {
+        if (null_walk && !(pl == 2 || pl == 3 || pl == 4 || pl == 8)) continue;
+        const double* row = a.fields + ((pl < 4 ? lrow_m : rrow_m) * kPostFields + kPlanes[pl]) * np;
+        const char* src = reinterpret_cast<const char*>(row + pt) + (lane & 1) * 4;
+        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + wave * 32), 4, 0, 0);
+      }
+    };
+    auto request = [&](size_t chunk) {
+      double* tile = tiles[chunk % kCpBufs];
+      stage_fields(1 + chunk * kCpChunk, tile);
+      stage_weights(1 + chunk * kCpChunk, tile);
+    };
+    for (int k = 0; k < kAhead; ++k) request(k);
+    for (size_t chunk = 0; chunk < n_chunks; ++chunk) {
+      const size_t rc0 = 1 + chunk * kCpChunk;
+      // requests of the kAhead - 1 later chunks may stay in flight: 9 field + 1 weight instructions each, wave 0 one more
+      // (the null walk: 4 field instructions)
+      if (null_walk) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 5) : "memory");
+      } else {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 11) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 10) : "memory");
+      }
+      __syncthreads();  // chunk's data is in LDS for every wave, and every wave is done with the buffer of chunk - 1
+      request(chunk + kAhead);
+      const double* __restrict__ t = tiles[chunk % kCpBufs];
+      const int c = grp * 4 + kpt;
+      const bool valid = rc0 + c < np;
+      const double* __restrict__ u = t + CpGeom<TILE>::kFieldTile + c * kCouplingWeights;
+      // a point past the grid contributes nothing: every left operand is linear in the left fields
+      const double lxr = valid ? t[0 * kCpPlane + mi * kCpChunk + c] : 0.0, lxh = valid ? t[1 * kCpPlane + mi * kCpChunk + c] : 0.0;
+      const double lpsi = valid ? t[2 * kCpPlane + mi * kCpChunk + c] : 0.0, lp = valid ? t[3 * kCpPlane + mi * kCpChunk + c] : 0.0;
+      const double rxr = t[4 * kCpPlane + mi * kCpChunk + c], rxh = t[5 * kCpPlane + mi * kCpChunk + c];
+      const double eb = u[CW_EB], rho = u[CW_RHO], mrot = u[CW_MROT], c1 = u[CW_C1], tr2 = u[CW_TR2];
+      if (null_walk) {
+        // l_zero += trap r^2 (psi_l rho'_r tea - (rho psi_l + p_l) xi_r adtea / x): one right field per output half
+        if (half == 0) {
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * u[CW_TEA]), t[8 * kCpPlane + mi * kCpChunk + c], acc[2], 0, 0, 0);
+        } else {
+          const double a0r = -(tr2 * ((u[CW_RX] * u[CW_ADTEA]) * (rho * lpsi + lp)));
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0r, rxr, acc[2], 0, 0, 0);
+        }
+      } else if (half == 0) {
+        const double vol = u[CW_VOL];
+        const double c_rr = ipr * u[CW_U1] + q2x2 * u[CW_U3], c_hh = iph * u[CW_U2] + q2hx2 * eb;
+        const double adr = vol * (lxr * c_rr + lxh * (eb * q2_hld)), adh = vol * (lxh * c_hh + lxr * (eb * q2_hrd));
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(adr, rxr, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(adh, rxh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * adr, rxr, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * adh, rxh, acc[1], 0, 0, 0);
+        const double c2 = u[CW_C2];
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(c2 * adr, rxr, acc[2], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(c2 * adh, rxh, acc[2], 0, 0, 0);
+        // l_zero, the terms with F and F^2 of (sig rho) (sig (ipr rr + iph hh) + c1 ipr (s + hh)), sig = F - mrot
+        const double tw = tr2 * rho, ci = c1 * ipr, m2 = -2.0 * mrot;
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxr * (m2 * ipr) + lxh * ci), rxr, acc[3], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxh * (m2 * iph + ci) + lxr * ci), rxh, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxr * ipr), rxr, acc[4], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxh * iph), rxh, acc[4], 0, 0, 0);
+      } else {
+        const double rtp = t[6 * kCpPlane + mi * kCpChunk + c], rtn = t[7 * kCpPlane + mi * kCpChunk + c];
+        const double rrho = t[8 * kCpPlane + mi * kCpChunk + c];
+        const double vol2 = u[CW_VOL2], vrot = u[CW_VOL2ROT];
+        const double c_s = ipr * u[CW_U4] + q2 * u[CW_U5], c_h2 = ipr * u[CW_U2] + k6x2 * eb;
+        const double bs = mrot * (vol2 * c_s), bh2 = mrot * (vol2 * c_h2);
+        const double arr = lxh * bs, arh = lxr * bs + lxh * bh2;
+        const double atp = vrot * (lxr * q_rt_p + lxh * q_ht_p), atn = vrot * (lxr * q_rt_n + lxh * q_ht_n);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(arr, rxr, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(arh, rxh, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(atp, rtp, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(atn, rtn, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * arr, rxr, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * arh, rxh, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * atp, rtp, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * atn, rtn, acc[1], 0, 0, 0);
+        // l_zero, the terms without F
+        const double ca = u[CW_ADTEA] + q2 * u[CW_ADTEB], cb = u[CW_TEA] + q2 * u[CW_TEB], rx = u[CW_RX];
+        const double pp = rho * lpsi, mc = mrot * (c1 * ipr), mm = mrot * mrot;
+        const double a0r = tr2 * (rho * (lxr * (mm * ipr) - lxh * mc) - (rx * ca) * (pp + lp));
+        const double a0h = tr2 * (rho * (lxh * (mm * iph - mc) - lxr * mc) + (rx * (u[CW_TEB] * q2_hrd)) * (pp - lp));
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0r, rxr, acc[2], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0h, rxh, acc[2], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * cb), rrho, acc[2], 0, 0, 0);
+      }
+    }
+    // the two groups' partial sums meet in LDS, then lz0 crosses to the wave that holds lz1 and lz2.  The staging tiles
+    // are free once the requests past the grid's end (issued to keep the count in flight constant) have landed.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double* __restrict__ red = &tiles[0][0];  // half 0: 5 outputs x 256 doubles, then half 1: 3 x 256
+    static_assert(kCpBufs * kCpTileDoubles >= 8 * 256, "reduction scratch fits the staging tiles");
+    const int n_out = half == 0 ? 5 : 3, red_base = half == 0 ? 0 : 5 * 256;
+    if (grp == 1) {
+#pragma unroll
+      for (int o = 0; o < 5; ++o)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (o < n_out) red[red_base + (o * 4 + v) * 64 + lane] = acc[o][v];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int o = 0; o < 5; ++o)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (o < n_out) acc[o][v] += red[red_base + (o * 4 + v) * 64 + lane];
+    }
+    __syncthreads();
+    double* __restrict__ lz0 = red;  // (every partial sum has been read)
+    if (grp == 0 && half == 1) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) lz0[v * 64 + lane] = acc[2][v];
+    }
+    __syncthreads();
+    if (grp == 0) {
+      const size_t mm2 = M * M;
+      const size_t rj = r0 + (size_t)(lane & 15);
+      const double F = a.freq[rj];
+      bool ok = true;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const size_t li = l0 + (size_t)((lane >> 4) + 4 * v);
+        const size_t at = li + rj * M;
+        if (null_walk) {
+          if (half == 0) {
+            const double lz = lz0[v * 64 + lane] + acc[2][v];
+            a.out[0 * mm2 + at] = 0.0; a.out[1 * mm2 + at] = 0.0; a.out[2 * mm2 + at] = 0.0;
+            a.out[5 * mm2 + at] = lz;
+            ok = ok && isfinite(lz);
+          } else {
+            a.out[3 * mm2 + at] = 0.0; a.out[4 * mm2 + at] = 0.0;
+          }
+        } else if (half == 0) {
+          const double lz = lz0[v * 64 + lane] + F * (acc[3][v] + F * acc[4][v]);
+          a.out[0 * mm2 + at] = acc[0][v]; a.out[1 * mm2 + at] = acc[1][v]; a.out[2 * mm2 + at] = acc[2][v];
+          a.out[5 * mm2 + at] = lz;
+          ok = ok && isfinite(acc[0][v]) && isfinite(lz);
+        } else {
+          a.out[3 * mm2 + at] = acc[0][v]; a.out[4 * mm2 + at] = acc[1][v];
+          ok = ok && isfinite(acc[0][v]);
+        }
+      }
+      if (!ok) atomicOr(a.flags, 1);
+    }
+    return;
+  }
+}
+#endif
+
 // One workgroup = one kCpTile x kCpTile tile of (left, right) pairs; its kCpWaves waves share the staged chunks (each
 // field value of the tile is fetched once per workgroup) and every wave walks its own 8 x 8 block.
 template <int TILE>
@@ -130,6 +374,13 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   // same argument a block of such pairs skips the products that contain them (about a quarter of the instructions).
   const bool off_diag = ipr == 0.0 && iph == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 && q_ht_p == 0.0 && q_ht_n == 0.0;
   const bool tame_block = a.tame != nullptr && a.weights_tame && __all(a.tame[lm] != 0 && a.tame[rm] != 0);
+#ifdef STORM_FAST_BUILD
+  if constexpr (TILE == 16) {
+    // FMA build: tiles of like degrees belong to the matrix-pipe walk (coupling_matrix_body, a launch of its own with
+    // its own, deeper staging ring -- inside this kernel the ring's LDS cost the vector walks half their occupancy)
+    if (cp_matrix_tile(a, l0, r0, lane).take) return;
+  }
+#endif
   // The walk of this WAVE's 8 x 8 block (wave-uniform): 0 = all factors zero, 1 = different degrees, 2 = the reference's
   // expression term by term, 3 = block outside the matrix (stages its share, no arithmetic).
   enum { kNull = 0, kOffDiag = 1, kFull = 2, kDead = 3 };
@@ -372,6 +623,16 @@ __global__ __launch_bounds__(64 * CpGeom<TILE>::kWaves, TILE == 16 ? STORM_CP_MI
   if (blockIdx.x >= tiles || blockIdx.y >= tiles) return;
   coupling_body<TILE>(a, blockIdx.x, blockIdx.y);
 }
+#ifdef STORM_FAST_BUILD
+// The tiles of like degrees (cp_matrix_tile): same grids as the kernels above, which leave those tiles alone.
+__global__ __launch_bounds__(256, 2) void coupling_matrix_kernel(CouplingArgs a) { coupling_matrix_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const CouplingArgs* __restrict__ table) {
+  const CouplingArgs a = table[blockIdx.z];
+  const size_t tiles = (a.n_modes + 15) / 16;
+  if (blockIdx.x >= tiles || blockIdx.y >= tiles) return;
+  coupling_matrix_body(a, blockIdx.x, blockIdx.y);
+}
+#endif
 }  // namespace
 
 hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
@@ -392,6 +653,13 @@ hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, s
   }
   if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
   else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
+#ifdef STORM_FAST_BUILD
+  if (tile == 16) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    coupling_matrix_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
+  }
+#endif
   return hipGetLastError();
 }
 
@@ -412,6 +680,13 @@ hipError_t launch_coupling(const CouplingArgs& a, int tile) {
   }
   if (tile == 8) coupling_kernel<8><<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
   else coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
+#ifdef STORM_FAST_BUILD
+  if (tile == 16) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    coupling_matrix_kernel<<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -240,6 +240,22 @@ def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
         return got
 
     got = check(fields, metric)
+    # FMA build: these 16 x 16 tiles of like degrees are the ones that take the matrix-pipe walk (v_mfma_f64_16x16x4, the
+    # integrands grouped by right field, l_zero as a polynomial in the right mode's frequency; the (1, 5) tiles its
+    # two-instruction form) -- m = 1 and rotation, so every weight and every power of the frequency is in play.  The FMA
+    # build's contract: 1e-12 of each matrix's largest magnitude (another association of the sum over the grid).
+    post.set_option("arithmetic", 1)
+    for tile in (16, 8):
+        post.set_option("coupling_tile", tile)
+        fast = post.coupling_matrices(ell, freq, fields, 1, metric)
+        for k in storm_amd.COUPLING_MATRICES:
+            scale = np.max(np.abs(got[k]))
+            assert scale > 0.0, k
+            assert np.max(np.abs(fast[k] - got[k])) <= 1e-12 * scale, (k, tile, np.max(np.abs(fast[k] - got[k])) / scale)
+        far16 = np.abs(ell[:, None].astype(int) - ell[None, :].astype(int)) > 2
+        for k in ("d_squared", "d_linear", "d_zero", "r_linear", "r_zero"):
+            assert np.all(fast[k][far16] == 0.0) and not np.any(np.signbit(fast[k][far16])), (k, tile)
+    post.set_option("arithmetic", 0)
     # 12 modes per degree: the 16 x 16 tiles straddle the degree blocks, so the four waves of one workgroup take
     # different walks (all factors zero / different degrees / full expression) around the same staged chunks
     pick = np.concatenate([np.arange(12), 16 + np.arange(12), 32 + np.arange(12)])
