@@ -1,5 +1,5 @@
 """Runs storm_coupling_matrices a few times on M modes (default 512) for rocprofv3 passes.
-usage: profile_coupling.py [M] [reps] [arithmetic]"""
+usage: profile_coupling.py [M] [reps] [arithmetic] [sorted: 1 = modes grouped by degree, as scans deliver them]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,8 @@ for ell in (0, 2):
     fields.append(got["fields"]); ells += [ell] * roots.size; freqs += list(roots)
 fields, ells, freqs = np.concatenate(fields), np.array(ells, dtype=np.uint64), np.array(freqs)
 sel = np.arange(M) % freqs.size
+if len(sys.argv) > 4 and int(sys.argv[4]):
+    sel = sel[np.argsort(ells[sel], kind="stable")]
 x = grid
 metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x ** 2,
           "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}

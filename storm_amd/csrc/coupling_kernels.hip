@@ -5,6 +5,7 @@
 #include "postprocess.hpp"
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include "shared_div.hpp"
 
@@ -633,6 +634,45 @@ __global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const Cou
   coupling_matrix_body(a, blockIdx.x, blockIdx.y);
 }
 #endif
+#ifdef STORM_FAST_BUILD
+// The two launches write disjoint tiles, and the vector walk of the few tiles that straddle degrees is a latency-bound
+// tail of milliseconds (one wave walks the grid point by point): the matrix launch goes to a side stream -- one per
+// device, created at first use and kept -- forked from and joined to the caller's stream by two events of this call, so
+// that both run at once (M = 1024, two degrees: 9.5 ms + 7.9 ms one after the other).
+hipStream_t cp_side_stream() {
+  static std::mutex mu;
+  static hipStream_t side[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!side[dev] && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) side[dev] = nullptr;
+  return side[dev];
+}
+// Runs `launch_side(stream)` beside what the caller puts on `main` between fork and join.
+struct CpFork {
+  hipStream_t main, side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  explicit CpFork(hipStream_t m) : main(m) {
+    side = cp_side_stream();
+    if (side && (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess ||
+                 hipEventRecord(fork, main) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess))
+      side = nullptr;  // (then everything stays on the caller's stream)
+  }
+  hipStream_t stream() const { return side ? side : main; }
+  hipError_t finish() {
+    hipError_t e = hipSuccess;
+    if (side) {
+      e = hipEventRecord(join, side);
+      if (e == hipSuccess) e = hipStreamWaitEvent(main, join, 0);
+    }
+    if (fork) (void)hipEventDestroy(fork);  // (destruction is deferred until the event has completed)
+    if (join) (void)hipEventDestroy(join);
+    fork = join = nullptr;
+    return e;
+  }
+};
+#endif
 }  // namespace
 
 hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
@@ -651,15 +691,19 @@ hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, s
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
-  else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
 #ifdef STORM_FAST_BUILD
   if (tile == 16) {
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    coupling_matrix_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
+    CpFork fk(stream);  // (after the prepasses: both launches read their results)
+    coupling_matrix_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, fk.stream()>>>(table);
+    hipError_t e = hipGetLastError();
+    coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
+    if (e == hipSuccess) e = hipGetLastError();
+    const hipError_t j = fk.finish();
+    return e != hipSuccess ? e : j;
   }
 #endif
+  if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
+  else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
   return hipGetLastError();
 }
 
@@ -678,15 +722,19 @@ hipError_t launch_coupling(const CouplingArgs& a, int tile) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  if (tile == 8) coupling_kernel<8><<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
-  else coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
 #ifdef STORM_FAST_BUILD
   if (tile == 16) {
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    coupling_matrix_kernel<<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
+    CpFork fk(a.stream);
+    coupling_matrix_kernel<<<dim3(tiles, tiles, 1), 256, 0, fk.stream()>>>(a);
+    hipError_t e = hipGetLastError();
+    coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
+    if (e == hipSuccess) e = hipGetLastError();
+    const hipError_t j = fk.finish();
+    return e != hipSuccess ? e : j;
   }
 #endif
+  if (tile == 8) coupling_kernel<8><<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
+  else coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
   return hipGetLastError();
 }
 
