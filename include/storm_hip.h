@@ -176,9 +176,11 @@ void storm_postproc_destroy(storm_postproc* post);
 /* Options of a post-processing handle (no counterpart in the reference).  "arithmetic": 0 (default) = the coupling
  * integrals of storm_coupling_matrices / storm_sweep_coupling_matrices keep the reference's association and are
  * bit-identical to its sequential sums (src/perturbed.rs:148-261); 1 = the FMA build (the same integrands re-associated,
- * about twice as fast): every matrix element within 1e-13 of the largest magnitude of its matrix
- * (tests/test_hip_coupling.py).  "coupling_tile": 0 (default, automatic), 8 or 16 modes per side of a workgroup's tile of
- * pairs; never changes a bit of the result.  The fields, norms and mode identification of storm_postprocess_batch are
+ * about twice as fast; 16 x 16 tiles whose left modes share one degree and whose right modes share one are summed on
+ * v_mfma_f64_16x16x4, four grid points per instruction): every matrix element within 1e-12 of the largest magnitude of
+ * its matrix (tests/test_hip_coupling.py; measured 1e-14).  "coupling_tile": 0 (default, automatic), 8 or 16 modes per
+ * side of a workgroup's tile of pairs; never changes a bit of the result in the parity build (in the FMA build only
+ * tiles of 16 take the matrix instructions).  The fields, norms and mode identification of storm_postprocess_batch are
  * always computed in the reference's arithmetic.
  * storm_sweep_coupling_matrices_batch follows the sweep's own "arithmetic" option. */
 int storm_postproc_set_option(storm_postproc* post, const char* key, int64_t value);
@@ -353,7 +355,8 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *   "arithmetic": 0 (default) parity build: separate multiply and add in the reference's order, results
  *                 bit-identical to the reference; 1 fast build: the same mathematics with FMA contraction
  *                 (v_fma_f64) and re-associated where that saves instructions (adjugate through 2x2 minors, stage
- *                 systems by LU, reciprocals by Newton steps, segment-parallel products: DESIGN.md section 5), ~3x
+ *                 systems by LU, reciprocals by Newton steps, segment-parallel products, the running 4x4 product on
+ *                 v_mfma_f64_4x4x4: DESIGN.md section 5), ~3x
  *                 the parity build's throughput.  Fast-mode contract (tests/test_hip_fast_mode.py):
  *                 |det_fast - det_ref| <= 1e-9 * max|det_ref| over the neighbouring grid points, identical
  *                 sign pattern / bracket indices on the BASELINE configs, roots within 1e-10 relative.
