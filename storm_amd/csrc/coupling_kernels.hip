@@ -102,7 +102,9 @@ PDEV CpMatrixTile cp_matrix_tile(const CouplingArgs& a, size_t l0, size_t r0, in
   return CpMatrixTile{tame, tame};
 }
 
-constexpr int kCpRing = 4;  // chunks staged at once in the matrix-pipe walk (kCpRing - 1 requested ahead)
+constexpr int kCpRing = 3;  // chunks staged at once in the matrix-pipe walk (kCpRing - 1 requested ahead).  Measured, M = 1024 of one
+// degree | 80 modes of three degrees repeated to M = 512 (few eligible tiles: latency counts): ring of 2: 8.2 | 7.7 ms, 3: 8.7 | 5.2 ms,
+// 4: 10.8 | 5.3 ms (42 KB of LDS: three workgroups per CU instead of five).
 
 PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
   constexpr int TILE = 16, kCpTile = 16, kCpPlane = CpGeom<16>::kPlane, kCpBufs = kCpRing;
