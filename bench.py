@@ -41,18 +41,35 @@ sys.path.insert(0, ROOT)
 # rotation.  See DESIGN.md section 5.
 FLOPS_PER_EVAL = {"colloc2": 610.1, "colloc4": 1396.1, "colloc6": 2694.1, "colloc8": 5048.1,
                   "magnus2": 1486.0, "magnus4": 1848.0, "magnus6": 2562.0, "magnus8": 3900.1}
-# HBM bytes per launch of the dominant kernels from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; the
-# summaries are under profiles/), keyed by (kernel, frequencies, arithmetic).  FETCH_SIZE (reported in KB) is doubled as
-# MI355X_MICROARCH.md prescribes for gfx950 -- a correction calibrated on 16-byte loads; these kernels read the coefficient
-# planes with 8-byte loads, so the figure is an upper bound.  The algorithmic bytes are ~2.7 MB (planes once + 16 B per
-# frequency); the surplus is one fetch of the planes and of their interval-major copy per XCD L2 and, in the FMA build,
-# 36 B/lane of register spills.
-TRAFFIC = {("det_hex<colloc8>", 10000, 0): 2 * 10872.8e3 + 156.25e3,          # profiles/r01_pmc_det_hex_colloc8.txt
-           ("det_hex<colloc4>", 100000, 1): 2 * 11621.1e3 + 11981.2e3,        # profiles/r02_pmc_det_hex_colloc4_fast.txt
-           ("det_hex<colloc4>", 100000, 0): 2 * 16873.3e3 + 781.25e3}          # profiles/r02_pmc_det_hex_colloc4_parity.txt
-# Flops the FMA build EXECUTES per evaluation (FMA = 2), counted in the ISA of its dominant loop: since the stage system is
-# solved by LU and the scalings are folded it does less arithmetic than the reference's formulation.
-EXECUTED_FLOPS_FAST = {"colloc4": 770.0}                                       # profiles/r02_isa_det_mix_colloc4_fast.txt
+# What the kernels EXECUTE -- FP64 flops per (frequency, interval) evaluation and HBM bytes per launch -- comes from rocprofv3
+# counter passes (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS,MFMA}_F64, FETCH_SIZE, WRITE_SIZE; scripts/gpu_r3_executed.sh condensed by
+# tools/executed_flops.py into profiles/r03_executed_flops.json, which records the commit it was taken at).  roofline.frac is
+# priced on THAT count; the reference formulation's count (FLOPS_PER_EVAL above: what the CPU reference would execute for the
+# same evaluations) gives the separately named `reference_equivalent` rate, which can pass the peak because the FMA build
+# re-formulates the step (LU stage solve, folded scalings, re-associated inverse: DESIGN.md section 5).
+with open(os.path.join(ROOT, "profiles", "r03_executed_flops.json")) as _fh:
+    EXECUTED = json.load(_fh)
+
+
+def executed_entry(group, arithmetic, **match):
+    """the counter-backed entry of profiles/r03_executed_flops.json for this launch (nearest batch size if not the same)"""
+    n_freq = match.pop("n_freq", None)
+    cand = [e for e in EXECUTED["entries"] if e["group"] == group and e["arithmetic"] == arithmetic
+            and all(e.get(k) == v for k, v in match.items())]
+    if not cand:
+        raise SystemExit(f"profiles/r03_executed_flops.json has no entry for {group} {arithmetic} {match}")
+    if n_freq is not None:
+        cand.sort(key=lambda e: abs(e["n_freq"] - n_freq))
+    return cand[0]
+
+
+def executed_source(e):
+    return {"file": "profiles/r03_executed_flops.json", "commit": EXECUTED.get("commit"), "group": e["group"],
+            "kernel": e["dominant_kernel"], "units_per_call": e["units_per_call"],
+            "executed_flops_per_unit": round(e["executed_flops_per_unit"], 2),
+            "counters_per_call": e["kernels"][e["dominant_kernel"]]["counters_per_call"]}
+
+
 PEAK_FP64_TFLOPS = 78.6     # MI355X vector FP64, FMA-counted (256 CU x 128 flop/clk x 2.4 GHz) = the dense FP64 MFMA peak
 UNFUSED_TFLOPS = 38.1       # measured chip-wide ceiling of separate v_mul_f64 / v_add_f64 (tools/fp64_microbench.hip)
 HBM_PEAK_GBS = 8000.0
@@ -214,17 +231,19 @@ def main():
                 "grid_points": N_FREQ, "checked": "in this run, before timing, against the parity build (which is "
                 "bit-identical to the reference: tests/test_hip_parity.py, tests/test_hip_api.py)"}
 
-    NOTE = {0: "algorithmic un-fused flops (oracle op count x evals per launch) / HIP-event duration of ONE whole-batch "
-               "launch run alone; parity arithmetic = the reference's separate mul and add (every f64 output bit-exact), "
-               f"whose measured chip-wide issue ceiling is {UNFUSED_TFLOPS} TFLOP/s (tools/fp64_microbench.hip), i.e. frac <= "
-               f"{UNFUSED_TFLOPS / PEAK_FP64_TFLOPS:.3f} by construction; frac_of_unfused_ceiling is the fraction of THAT",
-            1: "same kernel built with FMA contraction (option arithmetic=1). `achieved` keeps the reference formulation's "
-               "un-fused count (1396.1 flops per evaluation), so it is comparable between the two builds and between rounds "
-               "-- and can pass the peak, because this build re-formulates the step (LU stage solve, folded scalings, "
-               "re-associated inverse: DESIGN.md section 5) and executes 770 flops per evaluation, 128 of them the ordered product "
-               "as v_mfma_f64_4x4x4 (four frequencies per instruction; FP64 MFMA shares the vector FP64 pipe and its peak on "
-               "gfx950: tools/mfma64_microbench.hip); `executed` is the "
-               "hardware's own rate (flops counted in the ISA, profiles/r02_isa_det_mix_colloc4_fast.txt)"}
+    NOTE = {0: "achieved = EXECUTED FP64 flops (rocprofv3 counters: v_fma_f64 x 2, v_mul/v_add/transcendental x 1 per lane) per "
+               "launch / HIP-event duration of ONE whole-batch launch run alone; parity arithmetic = the reference's separate mul "
+               f"and add (every f64 output bit-exact), whose measured chip-wide issue ceiling is {UNFUSED_TFLOPS} TFLOP/s "
+               f"(tools/fp64_microbench.hip), i.e. frac <= {UNFUSED_TFLOPS / PEAK_FP64_TFLOPS:.3f} by construction; the counters do not "
+               "see the helper instructions of the IEEE divisions (v_div_scale / v_div_fmas / v_div_fixup), which is why the "
+               "executed count is below the reference formulation's 1396.1 although the arithmetic is the reference's",
+            1: "achieved = EXECUTED FP64 flops (rocprofv3 counters: v_fma_f64 x 2, v_mul/v_add/v_rcp x 1 per lane, "
+               "v_mfma_f64_4x4x4 x 512 per wave) per launch / HIP-event duration of ONE whole-batch launch run alone.  The FMA "
+               "build re-formulates the step (LU stage solve, folded scalings, re-associated inverse, ordered product on "
+               "v_mfma_f64_4x4x4: DESIGN.md section 5) and executes ~770 flops per evaluation where the reference's formulation "
+               "has 1396.1; `reference_equivalent` is the rate in the reference's count (comparable between builds and rounds; "
+               "not a hardware fraction, it can pass the peak).  FP64 MFMA shares the vector FP64 pipe and its peak on gfx950 "
+               "(tools/mfma64_microbench.hip)"}
 
     def roofline_of(arith):
         """The dominant kernel (det_hex<colloc4>, all of this rank's grid points in ONE launch) run alone, timed with
@@ -240,28 +259,37 @@ def main():
         h.set_option("hex_rounds", 1)
         kind = max(kt.items(), key=lambda kv: kv[1][0])[0]
         ms, cnt = kt[kind]
-        flops_per_launch = len(mine) * n_int * FLOPS_PER_EVAL["colloc4"] * reps / cnt
+        evals_per_launch = len(mine) * n_int * reps / cnt
+        ex = executed_entry("headline", "fast" if arith else "parity", scheme="colloc4", n_freq=len(mine))
+        flops_per_launch = evals_per_launch * ex["executed_flops_per_unit"]
         achieved = flops_per_launch / (ms / cnt * 1e-3) / 1e12
+        ref_eq = evals_per_launch * FLOPS_PER_EVAL["colloc4"] / (ms / cnt * 1e-3) / 1e12
         kernel = f"{kind}<colloc4>"
         pipe = ("fp64-valu (no MFMA: 4x4 products in the reference's order with separate mul and add, DESIGN.md section 2)"
                 if arith == 0 else
                 "fp64-valu + fp64-mfma, one pipe and one peak on gfx950 (the step matrices in v_fma_f64, the ordered "
                 "product in v_mfma_f64_4x4x4: DESIGN.md section 5)")
+        # HBM bytes per launch from the same counter file ((2 x FETCH_SIZE + WRITE_SIZE) x 1024, the guide's gfx950 correction);
+        # scaled by the batch size if this launch is not one of the profiled sizes
+        traffic = ex["kernels"][ex["dominant_kernel"]]["hbm_bytes_per_call"]
         r = {"bound": "compute", "pipe": pipe,
              "kernel": kernel, "achieved": round(achieved, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(achieved / PEAK_FP64_TFLOPS, 4), "traffic": TRAFFIC.get((kernel, len(mine), arith)),
+             "frac": round(achieved / PEAK_FP64_TFLOPS, 4), "traffic": traffic,
+             "traffic_note": f"HBM bytes per launch, rocprofv3 FETCH_SIZE/WRITE_SIZE passes on {ex['n_freq']} frequencies per launch; "
+                             "algorithmic bytes: coefficient planes once (2.7 MB) + 16 B per frequency",
              "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "flops_per_launch": flops_per_launch,
+             "executed_flops_per_eval": round(ex["executed_flops_per_unit"], 2), "executed_from": executed_source(ex),
+             "kernel_matches_profiled": kind in ex["dominant_kernel"] and ex["n_freq"] == len(mine),
+             "reference_equivalent": {"flops_per_eval": FLOPS_PER_EVAL["colloc4"], "achieved": round(ref_eq, 3), "unit": "TFLOP/s",
+                                      "ratio_to_peak": round(ref_eq / PEAK_FP64_TFLOPS, 4),
+                                      "what": "the reference formulation's un-fused flops for the same evaluations / time"},
              "frequencies_per_launch": len(mine), "note": NOTE[arith],
              "rocprof_row": "det_hex_kernel<colloc4,...> with 16 threads per frequency; in the FMA build, batches of >= 30 x "
                             "wave slots (~9e4) frequencies are ONE launch of det_mix_kernel<colloc4,...> (det_hex's 16-lane "
                             "groups and 4-lane column-owner groups side by side: DESIGN.md section 5) and a batch with a "
                             "remainder below a quarter wave round adds fast:seg_product + fast:chain_kernel for it"}
         if arith == 0:
-            r["frac_of_unfused_ceiling"] = round(achieved / UNFUSED_TFLOPS, 4)
-        else:
-            ex = achieved * EXECUTED_FLOPS_FAST["colloc4"] / FLOPS_PER_EVAL["colloc4"]
-            r["executed"] = {"flops_per_eval": EXECUTED_FLOPS_FAST["colloc4"], "achieved": round(ex, 3), "unit": "TFLOP/s",
-                             "frac": round(ex / PEAK_FP64_TFLOPS, 4)}
+            r["frac_of_unfused_ceiling"] = round(ref_eq / UNFUSED_TFLOPS, 4)
         return r
 
     def measure(arith, steps, warmup):
@@ -425,12 +453,18 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
             vd.det(freqs)
         ms, cnt = vd.kernel_times(reset=True)["det_hex"]
         vd.set_option("hex_rounds", 1)
-        ach = freqs.size * n_int * FLOPS_PER_EVAL["colloc8"] / (ms / cnt * 1e-3) / 1e12
+        ex = executed_entry("config2", "fast" if arith else "parity", scheme="colloc8", n_freq=freqs.size)
+        ach = freqs.size * n_int * ex["executed_flops_per_unit"] / (ms / cnt * 1e-3) / 1e12
+        ref_eq = freqs.size * n_int * FLOPS_PER_EVAL["colloc8"] / (ms / cnt * 1e-3) / 1e12
         cfg2["fast" if arith else "parity"] = {
             "evals_per_s": evals * n_int / dt, "ms_per_step": round(dt / steps * 1e3, 3), "modes_per_step": sum(modes),
             "roofline": {"bound": "compute", "pipe": "fp64-valu", "kernel": "det_hex<colloc8>", "achieved": round(ach, 3),
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_TFLOPS, 4),
-                         "avg_launch_ms": round(ms / cnt, 4), "traffic": TRAFFIC.get(("det_hex<colloc8>", 10000, arith))}}
+                         "avg_launch_ms": round(ms / cnt, 4),
+                         "traffic": ex["kernels"][ex["dominant_kernel"]]["hbm_bytes_per_call"],
+                         "executed_flops_per_eval": round(ex["executed_flops_per_unit"], 2), "executed_from": executed_source(ex),
+                         "reference_equivalent": {"flops_per_eval": FLOPS_PER_EVAL["colloc8"], "achieved": round(ref_eq, 3),
+                                                  "unit": "TFLOP/s", "ratio_to_peak": round(ref_eq / PEAK_FP64_TFLOPS, 4)}}}
     for v in views:
         v.set_option("arithmetic", 0)
     legs["config2"] = cfg2
@@ -475,15 +509,24 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
             raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
             raw.coupling_matrices(c_ell, c_f, c_fl, 0, metric)
             k_ms = raw.last_kernel_ms()
-            ach = M * M * (grid.size - 1) * 148.0 / (k_ms * 1e-3) / 1e12
-            cp["fast" if arith else "parity"] = {"bound": "compute", "pipe": "fp64-valu + fp64-mfma (one pipe)" if arith else "fp64-valu",
-                                                 "avg_launch_ms": round(k_ms, 3),
-                                                 "achieved": round(ach, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                                                 "frac": round(ach / PEAK_FP64_TFLOPS, 4)}
-        cp["note"] = ("achieved = the reference formulation's 148 flops per (pair, point) / time, as for the discriminant kernels; the "
-                      "FMA build's matrix walk executes 21 v_mfma_f64_16x16x4 per four points and tile = 42 flops per (pair, point) "
-                      "plus the weighted left operands, and is bound by staging the fields from L2 / HBM (16 x 16 tiles: 5 bytes per "
-                      "(pair, point)), not by the pipe: DESIGN.md section 10")
+            ex = executed_entry("coupling", "fast" if arith else "parity", modes=M)
+            terms = M * M * (grid.size - 1)
+            ach = terms * ex["executed_flops_per_unit"] / (k_ms * 1e-3) / 1e12
+            ref_eq = terms * 148.0 / (k_ms * 1e-3) / 1e12
+            cp["fast" if arith else "parity"] = {
+                "bound": "compute", "pipe": "fp64-valu + fp64-mfma (one pipe)" if arith else "fp64-valu",
+                "avg_launch_ms": round(k_ms, 3), "achieved": round(ach, 3), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_FP64_TFLOPS, 4), "traffic": ex["hbm_bytes_per_call"],
+                "executed_flops_per_pair_and_point": round(ex["executed_flops_per_unit"], 2),
+                "executed_from": {"file": "profiles/r03_executed_flops.json", "commit": EXECUTED.get("commit"),
+                                  "label": ex["label"], "kernels": ex["priced_kernels"]},
+                "reference_equivalent": {"flops_per_pair_and_point": 148.0, "achieved": round(ref_eq, 3), "unit": "TFLOP/s",
+                                         "ratio_to_peak": round(ref_eq / PEAK_FP64_TFLOPS, 4)}}
+        cp["note"] = ("achieved = EXECUTED flops (rocprofv3 FP64 instruction counters over all launches of the call) / HIP-event time "
+                      "around them; reference_equivalent = the reference formulation's 148 flops per (pair, point) / time.  The FMA "
+                      "build's matrix walk executes 21 v_mfma_f64_16x16x4 per four points and tile = 42 flops per (pair, point) "
+                      "plus the weighted left operands, and is bound by staging the fields from L2 / HBM, not by the pipe: "
+                      "DESIGN.md section 10")
         legs["coupling_integrals"] = cp
         del raw, c_fl, got
     del views, solvers

@@ -15,10 +15,10 @@ NAMES = ["colloc2", "colloc4", "colloc6", "colloc8", "magnus2", "magnus4", "magn
 
 def short(name):
     name = re.sub(r"\.kd$", "", name)
-    m = re.match(r"(?:void )?storm(_fast)?::(\w+)(?:<([^>]*)>)?\(", name)
+    m = re.match(r"(?:void )?storm(_fast)?::(?:\(anonymous namespace\)::)?(\w+)(?:<([^>]*)>)?\(", name)
     if m:  # demangled
         targs = [a.strip() for a in (m.group(3) or "").split(",") if a.strip()]
-        if targs and targs[0].isdigit() and not m.group(2).startswith("eigen"):  # (eigen kernels: an ell class, not a scheme)
+        if targs and targs[0].isdigit() and not m.group(2).startswith(("eigen", "coupling")):  # (eigen kernels: an ell class, not a scheme)
             targs[0] = NAMES[int(targs[0])]
         targs = [{"true": "1", "false": "0"}.get(a, a) for a in targs]
         return ("fast:" if m.group(1) else "") + m.group(2) + (f"<{','.join(targs)}>" if targs else "")
