@@ -97,13 +97,19 @@ int storm_det_batch_device(storm_solver* solver, const double* d_freq, size_t n,
 int storm_det_scaled_batch(storm_solver* solver, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out);
 
 /* storm_det_batch_device for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
- * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels, same choice between
- * them and same results as storm_det_batch_device with default options, but the two scratch areas they need (the
- * singular-stage flag word, the segment transfer matrices of the "segments" path) live in a file-scope device array of
- * STORM_NOALLOC_SCRATCH_BYTES that every GPU holds once per process, so the call reaches no hipMalloc / hipFree /
- * hipHostMalloc and creates no event or stream.  Limits: n <= STORM_NOALLOC_MAX_N, and the segment transfer matrices of
- * one call (128 B per (frequency, segment) pair; only batches below "hex_min_n" in the FMA build have any) must fit the
- * scratch -- always true for the automatic segment length; STORM_ERR_CAPACITY otherwise.  A singular stage matrix shows
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels and the same choice
+ * between them as storm_det_batch_device (options "path", "fused_min_n", "quad_min_n", "hex_min_n", "segments" included),
+ * with one difference: the staged path (step matrices in a buffer of 128 B per (frequency, interval): "path" = 2, or a
+ * small batch that has no segment plan -- parity build, or fewer than 64 intervals) is replaced by det_hex, which forms
+ * the same ordered product.  Results are bit-identical to storm_det_batch_device in the parity build on every path, and
+ * in the FMA build wherever both take the same kernels (always, except where det_hex replaces the staged path: there the
+ * FMA build's two kernels agree to its tolerance contract).  The two scratch areas the kernels need -- the
+ * singular-stage flag word, and the segment transfer matrices (128 B per (frequency, segment) pair) of the FMA build's
+ * segment path, which small batches AND the last partial wave round of large batches take -- live in a file-scope device
+ * array of STORM_NOALLOC_SCRATCH_BYTES that every GPU holds once per process, so the call reaches no hipMalloc / hipFree /
+ * hipHostMalloc and creates no event or stream.  A segment plan whose matrices would not fit the scratch (possible only
+ * with a forced "segments" length) is dropped and det_hex takes those frequencies.  Limit: n <= STORM_NOALLOC_MAX_N,
+ * STORM_ERR_CAPACITY otherwise.  A singular stage matrix shows
  * as NaN in d_det_out (no status is read back).  hip_stream NULL: the solver's own stream, and the call returns after
  * the work completed; otherwise asynchronous on that stream.  All allocation-free calls on one GPU share the scratch:
  * calls that overlap on one GPU (different streams or handles) race; calls on one stream are safe. */

@@ -91,8 +91,8 @@ SDEV M4 point_matrix(const Coef& t, int j, double lambda, double f, const FreqTe
     if constexpr (!UNIFORM) ft = freq_terms<false>(f, t(F_ROTM, j), lambda);
     const double dl = a.v[2 * 4 + 3];
     const double q = dl * ft.rel_rot;
-#ifdef STORM_FAST_BUILD
-    const double x = t(F_DL2, j) * fast_recip(ft.w_rsq * dc1);
+#ifdef STORM_FAST_MATH
+    const double x = t(F_DL2, j) * fast_recip_guarded(ft.w_rsq * dc1);
 #else
     const double x = t(F_DL2, j) / (ft.w_rsq * dc1);
 #endif

@@ -44,7 +44,7 @@ SDEV M4 m4_mul(const M4& a, const M4& b) {
   return c;
 }
 
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
 // FMA build: products with the point matrices A_j = (dx/x) A(x_j, omega), whose entries (2,0), (2,1) and (0,3) are
 // structurally zero (Rotating1D::eval / add_frequency never write them, src/system/adiabatic.rs:78-152).  ZA / ZB: bit
 // c*4+r set = entry (r, c) of the left / right factor is a structural zero; the products with them are skipped (the parity
@@ -119,13 +119,27 @@ SDEV M4 m4_minus_eye(const M4& a) {  // a - eye
   return c;
 }
 
+#ifdef STORM_FAST_MATH
+SDEV double fast_recip(double x);
+// fast_recip with IEEE's special cases restored by one v_div_fixup_f64: 1/0 = inf, 1/inf = 0, 1/denormal (fast_recip alone
+// gives NaN there: its seed is inf or 0 and the Newton step forms 0 * inf).  For operands the data can drive to the edge --
+// add_frequency's omega_r^2 c1, which is 0 at omega = m Omega -- so that the FMA build's non-finite pattern is the parity
+// build's (tests/test_hip_fast_mode.py::test_fast_zero_frequency_edge).
+SDEV double fast_recip_guarded(double x) { return __builtin_amdgcn_div_fixup(fast_recip(x), x, 1.0); }
+#endif
+
 // Cofactor inverse.  `ok` is false when det == 0 (the reference would panic on
 // try_inverse().unwrap()); the caller turns that into a NaN result + error flag.
-#ifdef STORM_FAST_BUILD
+SDEV M4 m4_inverse_ref(const M4& a, bool& ok);
+#ifdef STORM_FAST_MATH
 // FMA build: 1/x from the hardware seed (v_rcp_f64, ~2^-26) and two Newton steps: 6 instructions, against ~17 for the IEEE
 // division sequence (v_div_scale x2, rcp, the fma chain, v_div_fmas, v_div_fixup).  Error <= ~1 ulp instead of 1/2 ulp; no
-// rescue for denormal or near-overflow x (the result is then inf or NaN, which the callers flag like a singular matrix).
+// rescue for zero, infinite, denormal or near-overflow x (the result is then NaN): used where the caller flags those itself
+// (the determinant of an inverse: `ok`; the pivots of lu4_factor: its acceptance test); fast_recip_guarded elsewhere.
 SDEV double fast_recip(double x) {
+#ifdef STORM_FAST_IEEE_DIV  // (attribution experiment, tests/attribution_config3.py)
+  return 1.0 / x;
+#endif
   double r = __builtin_amdgcn_rcp(x);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -137,6 +151,9 @@ SDEV double fast_recip(double x) {
 // instead of ~210.  Re-associates the cofactors, so it is not offered in the parity build.  Returns scale * a^-1 (the factor
 // goes into the reciprocal of the determinant).
 SDEV M4 m4_inverse_fast(const M4& a, bool& ok, double scale = 1.0) {
+#ifdef STORM_FAST_REF_INVERSE  // (attribution experiment: the reference's sixteen cofactors, then the scale)
+  return m4_scale(m4_inverse_ref(a, ok), scale);
+#endif
   auto e = [&](int r, int c) { return a.v[c * 4 + r]; };
   const double s0 = e(0, 0) * e(1, 1) - e(1, 0) * e(0, 1), s1 = e(0, 0) * e(1, 2) - e(1, 0) * e(0, 2);
   const double s2 = e(0, 0) * e(1, 3) - e(1, 0) * e(0, 3), s3 = e(0, 1) * e(1, 2) - e(1, 1) * e(0, 2);
@@ -216,7 +233,11 @@ SDEV void lu4_solve(const Lu4& f, double* x) {
 template <int N>
 SDEV void m4_solve_n(const M4& a, M4 (&x)[N], bool& ok) {
   Lu4 f;
+#ifdef STORM_FAST_NO_LU  // (attribution experiment: always the adjugate inverse)
+  if (false) {
+#else
   if (lu4_factor(a, f)) {
+#endif
 #pragma unroll
     for (int k = 0; k < N; ++k)
 #pragma unroll
@@ -235,9 +256,13 @@ SDEV M4 m4_solve(const M4& a, const M4& b, bool& ok) {
 #endif
 
 SDEV M4 m4_inverse(const M4& a, bool& ok) {
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
   return m4_inverse_fast(a, ok);
+#else
+  return m4_inverse_ref(a, ok);
 #endif
+}
+SDEV M4 m4_inverse_ref(const M4& a, bool& ok) {
   const double* m = a.v;
   M4 o;
   o.v[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
@@ -321,7 +346,7 @@ SDEV M4 m4_exp(M4 a) {
     const double sc = __builtin_ldexp(1.0, -exponent);
     a = m4_scale(a, sc);
   }
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
   constexpr unsigned kZ = SPARSE_IN ? kPointMatrixZeros : 0u;
   const M4 a2 = m4_mul_sparse<kZ, kZ>(a, a);
   const M4 a3 = m4_mul_sparse<0u, kZ>(a2, a);

@@ -47,7 +47,7 @@ inline void scheme_abscissae(int scheme, double out[4]) {
 }
 
 // Products whose factors are point matrices: a_i * a_j and a_i * X.
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
 SDEV M4 m4_mul_aa(const M4& a, const M4& b) { return m4_mul_sparse<kPointMatrixZeros, kPointMatrixZeros>(a, b); }
 SDEV M4 m4_mul_ax(const M4& a, const M4& x) { return m4_mul_sparse<kPointMatrixZeros, 0u>(a, x); }
 #else
@@ -65,13 +65,13 @@ constexpr double colloc_jump_factor() {
 template <int SCHEME>
 SDEV M4 colloc_jump(const M4* a, bool& ok) {
   if constexpr (SCHEME == kColloc2) {
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     return a[0];
 #endif
     return m4_scale(a[0], 0.5);
   } else if constexpr (SCHEME == kColloc4) {
     const M4 a2a1 = m4_mul_aa(a[1], a[0]);
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     // k2 = (I + a2a1/12)^-1 rhs = 12 z with (12 I + a2a1) z = rhs, solved by LU; k1 + k2 = a1 + 12 (z + c1 a1 z)
     M4 st = a2a1;
     st.v[0] += 12.0; st.v[5] += 12.0; st.v[10] += 12.0; st.v[15] += 12.0;
@@ -96,21 +96,21 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 f3 = m4_sub(m4_scale(a[2], d32), m4_scale(a3a1, d12 * d31));
     const M4 o3 = m4_sub(m4_sub(a[2], m4_scale(a3a1, d31)), m4_mul(f3, o2));
     const M4 l3 = m4_sub(m4_eye_minus(m4_scale(a3a1, d13 * d31)), m4_mul(f3, l2));
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     const M4 k3 = m4_solve(l3, o3, ok);
 #else
     const M4 k3 = m4_mul(m4_inverse(l3, ok), o3);
 #endif
     const M4 k2 = m4_sub(o2, m4_mul(l2, k3));
     const M4 k1 = m4_mul_ax(a[0], m4_sub(m4_eye_minus(m4_scale(k2, d12)), m4_scale(k3, d13)));
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     return m4_add(m4_add(k1, k3), m4_scale(k2, (2. / 9.) / (5. / 36.)));
 #endif
     return m4_add(m4_add(m4_scale(k1, 5. / 36.), m4_scale(k2, 2. / 9.)), m4_scale(k3, 5. / 36.));
   } else {
     static_assert(SCHEME == kColloc8, "collocation scheme expected");
     const M4 a2a1 = m4_mul_aa(a[1], a[0]), a3a1 = m4_mul_aa(a[2], a[0]), a4a1 = m4_mul_aa(a[3], a[0]);
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     // the stage systems are solved by LU (m4_solve_n) instead of inverse + product
     M4 s2[3] = {m4_sub(m4_scale(a[1], kD23), m4_scale(a2a1, kD21 * kD13)),
                 m4_sub(m4_scale(a[1], kD24), m4_scale(a2a1, kD21 * kD14)), m4_sub(a[1], m4_scale(a2a1, kD21))};
@@ -144,7 +144,7 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
     const M4 k2 = m4_sub(m4_sub(r2, m4_mul(u24, k4)), m4_mul(u23, k3));
     const M4 k1 = m4_sub(m4_sub(m4_sub(a[0], m4_mul_ax(m4_scale(a[0], kD14), k4)), m4_mul_ax(m4_scale(a[0], kD13), k3)),
                          m4_mul_ax(m4_scale(a[0], kD12), k2));
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
     return m4_add(m4_add(k1, k4), m4_scale(m4_add(k2, k3), kW2 / kW1));
 #endif
     return m4_add(m4_add(m4_add(m4_scale(k1, kW1 / 2.), m4_scale(k2, kW2 / 2.)), m4_scale(k3, kW2 / 2.)),
@@ -156,7 +156,7 @@ SDEV M4 colloc_jump(const M4* a, bool& ok) {
 // SA / SB: the left / right factor of [a, b] has the point matrices' zero pattern.
 template <bool SA, bool SB>
 SDEV M4 magnus_commutator(const M4& a, const M4& b) {
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
   constexpr unsigned ZA = SA ? kPointMatrixZeros : 0u, ZB = SB ? kPointMatrixZeros : 0u;
   return m4_sub(m4_mul_sparse<ZA, ZB>(a, b), m4_mul_sparse<ZB, ZA>(b, a));
 #else
@@ -205,7 +205,7 @@ SDEV M4 magnus_omega(const M4* a) {
   }
 }
 
-#ifdef STORM_FAST_BUILD
+#ifdef STORM_FAST_MATH
 // FMA build, collocation schemes: with jump = c S the transfer matrix is (-right^-1) * left with right = c S - I and
 // left = right + 2 I, i.e. -I - 2 right^-1 = -I - (2/c) (S - I/c)^-1: no product (same matrix, re-associated).
 // colloc_shifted returns S - I/c, step_from_shifted inverts it.  (Factoring S - I/c and applying the solve to the columns
@@ -234,10 +234,13 @@ SDEV M4 step_matrix(const M4* a, bool& ok) {
   if constexpr (scheme_is_magnus(SCHEME)) {
     return m4_exp<SCHEME == kMagnus2>(magnus_omega<SCHEME>(a));
   } else {
-#ifdef STORM_FAST_BUILD
+#if defined(STORM_FAST_MATH) && !defined(STORM_FAST_NO_FOLD)
     return step_from_shifted<SCHEME>(colloc_shifted<SCHEME>(a, ok), ok);
 #else
-    const M4 jump = colloc_jump<SCHEME>(a, ok);
+    M4 jump = colloc_jump<SCHEME>(a, ok);
+#ifdef STORM_FAST_MATH  // (attribution experiment: the wrapper's product form on jump = c S)
+    jump = m4_scale(jump, colloc_jump_factor<SCHEME>());
+#endif
     M4 l, r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

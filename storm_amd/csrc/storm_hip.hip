@@ -1464,14 +1464,23 @@ int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t
     int* flags = reinterpret_cast<int*>(s->scratch);
     double* partial = reinterpret_cast<double*>(s->scratch + kScratchFlagBytes);
     const size_t n_int = s->sys.n_int;
-    // the automatic choice of storm_det_batch_device, minus the path that stages step matrices in a buffer of its own
-    const SegPlan plan = n < s->hex_min_n ? plan_segments(s, n, n_int) : SegPlan{};
+    // The kernel choice of storm_det_batch_device (det_device), options `path`, `fused_min_n`, `quad_min_n`, `hex_min_n`
+    // and `segments` included, with two differences forced by the fixed scratch: the staged path (build_steps + chain,
+    // `path` = 2 or a small batch without a segment plan) needs a buffer of 128 B per (frequency, interval) and is replaced
+    // by det_hex, which computes the same ordered product; and a segment plan whose transfer matrices do not fit the
+    // scratch is dropped in favour of det_hex as well (not an error).
+    const bool fused = s->path == 1 || (s->path == 0 && (n >= s->fused_min_n || n_int == 0));
+    const bool quad = s->path == 3 || (s->path == 0 && !fused && n >= s->quad_min_n);
+    const bool hex = s->path == 4 || (s->path == 0 && !fused && !quad && n >= s->hex_min_n);
+    const auto fits = [&](const SegPlan& p, size_t m) { return m * size_t(p.n_seg) * 16 * sizeof(double) <= kScratchPartialBytes; };
+    SegPlan plan = (s->path == 0 && !fused && !quad && !hex) ? plan_segments(s, n, n_int) : SegPlan{};
+    if (plan.n_seg && !fits(plan, n)) plan = SegPlan{};
     SegPlan rest_plan;
-    const size_t n_hex = (plan.n_seg || n_int == 0) ? n : hex_whole_rounds(s, n, rest_plan);
-    if ((plan.n_seg && n * size_t(plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes) ||
-        (rest_plan.n_seg && (n - n_hex) * size_t(rest_plan.n_seg) * 16 * sizeof(double) > kScratchPartialBytes))
-      fail(STORM_ERR_CAPACITY, "the segment transfer matrices of this call exceed the allocation-free scratch "
-                               "(STORM_NOALLOC_SCRATCH_BYTES): fewer frequencies per call, or longer segments");
+    size_t n_hex = n;
+    if (!plan.n_seg && !fused && !quad && s->path != 2) {
+      n_hex = hex_whole_rounds(s, n, rest_plan);
+      if (rest_plan.n_seg && !fits(rest_plan, n - n_hex)) { rest_plan = SegPlan{}; n_hex = n; }
+    }
     if (st != s->stream) hip_check(hipStreamWaitEvent(st, s->ready, 0), "hipStreamWaitEvent");
     hip_check(hipMemsetAsync(flags, 0, 2 * sizeof(int), st), "flags memset");  // the scratch keeps the last call's contents
     LaunchArgs a = make_args(s, d_freq, n, d_out, st, flags);
@@ -1482,8 +1491,11 @@ int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t
       reduced.n_int = size_t(plan.n_seg);
       hip_check(storm_fast::launch_chain(reduced, s->ell0, d_freq, n, partial, d_out, st), "chain launch");
       count_launch(s, 2);
-    } else if (n_int == 0) {
+    } else if (fused) {
       hip_check(g_launch_fused[s->arith][s->scheme](a), "det_fused launch");
+      count_launch(s);
+    } else if (quad) {
+      hip_check(g_launch_quad[s->arith][s->scheme](a), "det_quad launch");
       count_launch(s);
     } else {
       a.n = n_hex;

@@ -11,6 +11,14 @@
 #ifndef STORM_NS
 #define STORM_NS storm
 #endif
+// STORM_FAST_BUILD selects the FMA build's kernels and launch choices; STORM_FAST_MATH its re-formulated arithmetic
+// (mat4.hpp, steppers.hpp, device_system.hpp).  The two only differ in the variant libraries of the attribution
+// experiment (tests/attribution_config3.py), which switch the re-formulations off -- all of them with
+// -DSTORM_FAST_PARITY_FORMULAS (contraction only), or one at a time with -DSTORM_FAST_IEEE_DIV, -DSTORM_FAST_NO_LU,
+// -DSTORM_FAST_REF_INVERSE, -DSTORM_FAST_NO_FOLD.
+#if defined(STORM_FAST_BUILD) && !defined(STORM_FAST_PARITY_FORMULAS)
+#define STORM_FAST_MATH 1
+#endif
 
 namespace storm {
 

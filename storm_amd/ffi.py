@@ -10,7 +10,9 @@ _dp = C.POINTER(C.c_double)
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libstorm_hip.so")
+    """libstorm_hip.so in-tree; STORM_HIP_LIBRARY names another BUILD of the same library (the variant builds of
+    tests/attribution_config3.py) -- never anything but a HIP build: there is no CPU fallback."""
+    return os.environ.get("STORM_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libstorm_hip.so")
 
 
 class StormError(RuntimeError):

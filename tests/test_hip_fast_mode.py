@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DET_TOL, ROOT_TOL, VEC_TOL = 1e-9, 1e-10, 1e-7
 
 
-def hip_from_oracle(o, arithmetic):
+def hip_from_oracle(o, arithmetic=0):
     import storm_amd
     h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
     h.set_option("arithmetic", arithmetic)
@@ -78,6 +78,40 @@ def test_fast_rotation_and_inverse_grid(oracle, golden_dir):
         got = fast.det(f)
         assert np.all(np.abs(got - ref) <= DET_TOL * local_scale(ref))
         assert np.array_equal(np.signbit(got), np.signbit(ref))
+
+
+@pytest.mark.parametrize("scheme", ["colloc4", "colloc6", "magnus4"])
+def test_fast_zero_frequency_edge(oracle, golden_dir, scheme):
+    """Grid points where add_frequency's omega_r^2 c1 is exactly zero -- omega = m Omega (co-rotating frequency 0) and, without
+    rotation, omega = 0: the reference divides by it (src/system/adiabatic.rs:141-146) and gets inf, the FMA build's
+    reciprocal must not turn that into something the sign-swap filter treats differently (a NaN always "differs" and raises
+    the invalid flag, an infinity carries a sign): same finite pattern, same brackets, same flag as the parity build."""
+    import storm_amd
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_tams.npz"))
+    for rot, ell, m, edge in ((0.1, 2, 1, 0.1), (0.0, 2, 0, 0.0), (0.25, 3, 2, 0.5)):
+        model.set_rotation_constant(rot)
+        o = oracle.Solver(model, ell, m, scheme, model.field("r_coord"))
+        f = np.sort(np.concatenate([oracle.linspace(1.0, 8.0, 37), [edge, edge + 0.25, edge + 0.5]]))
+        out = {}
+        for arith in (0, 1):
+            h = hip_from_oracle(o, arithmetic=arith)
+            try:
+                res, dets, inv = h.scan_and_optimize(f, oracle.relative_to_ulp(1e-8))
+            except storm_amd.StormError as e:      # (a non-finite value inside a refinement: the reference asserts)
+                res, dets, inv = e.code, h.det(f), None
+            out[arith] = (res, dets, inv)
+        (pres, pdets, pinv), (fres, fdets, finv) = out[0], out[1]
+        assert not np.isfinite(pdets[np.searchsorted(f, edge)])                 # the edge is what it is meant to be
+        assert np.array_equal(np.isfinite(pdets), np.isfinite(fdets)), (rot, ell, m)
+        assert np.array_equal(np.isnan(pdets), np.isnan(fdets)), (rot, ell, m)
+        fin = np.isfinite(pdets)
+        assert np.array_equal(np.signbit(pdets[~np.isnan(pdets)]), np.signbit(fdets[~np.isnan(pdets)]))
+        assert np.all(np.abs(fdets[fin] - pdets[fin]) <= DET_TOL * local_scale(np.where(fin, pdets, 0.0))[fin])
+        assert pinv == finv
+        if isinstance(pres, list):
+            assert [b["index"] for b in pres] == [b["index"] for b in fres]
+        else:
+            assert pres == fres
 
 
 @pytest.mark.parametrize("scheme", ["colloc2", "colloc4", "colloc6", "colloc8"])

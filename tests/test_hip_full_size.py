@@ -100,20 +100,47 @@ def test_config3_polytrope_full_grid_parity_build_bit_exact(config3_polytrope):
     assert same_bits(rdet, gdet[sel]) and same_bits(rvec, gvec[sel])
 
 
-def test_config3_polytrope_full_grid_fast_build_brackets_identical(config3_polytrope):
+def one_ulp_data_sensitivity(oracle, o, f, roots):
+    """How far the ORACLE's own results move when one input field moves by ONE ulp per point (seeded random signs): the
+    conditioning of the reference's value with respect to its data.  Returns (discriminants: max |d' - d| / local scale over
+    `f`, eigenvectors: max-norm relative change at `roots`)."""
+    ref = o.det(f, threads=16)
+    scale = local_scale(ref)
+    _, rvec = o.eigenvector(roots, threads=16)
+    rng = np.random.default_rng(1)
+    det_s, vec_s = 0.0, 0.0
+    for name in ("a_star", "gamma1"):
+        m2 = oracle.Model.polytrope(3.0, 5.0 / 3.0, XI1_N3 / 9999.0)
+        v = m2.field(name)
+        up = rng.integers(0, 2, v.size).astype(bool)
+        m2.set_field(name, np.where(up, np.nextafter(v, np.inf), np.nextafter(v, -np.inf)))
+        o2 = oracle.Solver(m2, o.ell, o.m, o.scheme, m2.grid(1))
+        det_s = max(det_s, float(np.max(np.abs(o2.det(f, threads=16) - ref) / scale)))
+        _, v2 = o2.eigenvector(roots, threads=16)
+        vec_s = max(vec_s, float(np.max(np.max(np.abs(v2 - rvec), axis=1) / np.max(np.abs(rvec), axis=1))))
+    return det_s, vec_s
+
+
+def test_config3_polytrope_full_grid_fast_build_brackets_identical(oracle, config3_polytrope):
     o, f, ulp, ref = config3_polytrope
-    # Discriminant tolerance 2e-6 on THIS model (1e-9 everywhere else): towards the surface of the 10^4-point n = 3
-    # polytrope V -> inf, the Colloc4 stage matrices reach |A| ~ 1e8 and their cofactor inverses amplify any rounding
-    # difference; measured |det_fast / det_ref - 1| <= 4.4e-7 (Colloc2: 8e-11, Colloc6: 1.4e-8 on the same model,
-    # scripts/fast_vs_parity_config3.py).  The factor is multiplicative, so it vanishes with the discriminant at a
-    # root: signs and bracket indices are identical and the roots agree to 1.1e-12 (bound asserted: 1e-10).
-    h, fres = check_fast_full(o, f, ulp, ref, det_tol=2e-6)
+    # The bar on THIS model is derived, not chosen: towards the surface of the 10^4-point n = 3 polytrope V and A* grow like
+    # 1/(1 - x) (1.8e8 at the last point) and the reference's own discriminant is determined by its input data only to a few
+    # 1e-7 -- ONE ulp on a_star or gamma1 moves the oracle's value by 3-4e-7 of the local scale (one ulp on the frequency:
+    # 7e-13).  No arithmetic that rounds differently can agree better than that, whatever its formulation:
+    # profiles/r03_attribution_config3.txt has the FMA build with each re-formulation (LU stage solve, Newton reciprocal,
+    # Laplace-expansion inverse, folded wrapper) switched off in turn and with the reference's formulas under contraction
+    # alone -- 4.0e-7 to 5.8e-7 every time, 4.0e-7 as shipped.  So: bar = max(1e-9, 4 x the measured one-ulp sensitivity).
+    # The factor is multiplicative in the discriminant, so it vanishes at a root: signs and bracket indices are identical
+    # and the roots agree to 1.1e-12 (bound asserted: 1e-10).
     roots = np.array([b["root"] for b in ref[0]])
     sel = np.arange(len(roots))[:: max(1, len(roots) // 4)]
+    det_s, vec_s = one_ulp_data_sensitivity(oracle, o, oracle.linspace(1.0, 25.0, 2000), roots[sel])
+    assert 1e-8 < det_s < 2e-6, det_s          # (if this model ever becomes well-conditioned the plain contract applies)
+    h, fres = check_fast_full(o, f, ulp, ref, det_tol=max(DET_TOL, 4.0 * det_s))
     _, rvec = o.eigenvector(roots[sel], threads=16)
     _, fvec = h.eigenvector(roots[sel])
     err = np.max(np.abs(fvec - rvec), axis=1) / np.max(np.abs(rvec), axis=1)
-    assert np.all(err <= 2e-6), err.max()   # (1e-7 on the other models; same amplification as the discriminants here)
+    assert np.all(err <= max(1e-7, 4.0 * vec_s)), (err.max(), vec_s)   # (1e-7 on the other models)
 
 
 @pytest.mark.parametrize("scheme", ["colloc4", "magnus2"])
@@ -160,6 +187,44 @@ def test_config2_all_six_scans_full_grid(oracle, golden_dir, scheme, ell):
     ulp = oracle.relative_to_ulp(1e-8)
     ref = o.scan_and_optimize(f, ulp, threads=16)       # 6.2e7 evaluations
     assert len(ref[0]) > 10
+    check_parity_full(o, f, ulp, ref)
+    check_fast_full(o, f, ulp, ref)
+
+
+# ---------------------------------------------------------------------------------------------- configs 4 and 5
+def rotating_tams(oracle, golden_dir):
+    model = oracle.Model.from_gsm_npz(os.path.join(golden_dir, "gsm_tams.npz"))
+    model.set_rotation_constant(0.1)        # `set-rotation-constant 0.1`, src/main.rs:785-788
+    return model
+
+
+@pytest.mark.parametrize("m", [-1, 1])
+@pytest.mark.parametrize("ell", [1, 2, 3])
+def test_config4_rotating_full_grid_both_builds(oracle, golden_dir, ell, m):
+    """BASELINE config 4: tams with rot = 0.1, ell = 1..3, m = -1, +1, Colloc4, 10^4 frequencies: the rot != 0 branch of
+    add_frequency and of the inner boundary (src/system/adiabatic.rs:136-148,164-168).  Parity build bit-exact on every
+    point; FMA build: identical sign pattern and bracket index list, roots <= 1e-10, against the ORACLE."""
+    model = rotating_tams(oracle, golden_dir)
+    o = oracle.Solver(model, ell, m, "colloc4", model.field("r_coord"))
+    f = oracle.linspace(1.0, 25.0, 10000)
+    ulp = oracle.relative_to_ulp(1e-8)
+    ref = o.scan_and_optimize(f, ulp, threads=16)
+    assert len(ref[0]) > 10
+    check_parity_full(o, f, ulp, ref)
+    check_fast_full(o, f, ulp, ref)
+
+
+@pytest.mark.parametrize("ell", [0, 2, 4])
+def test_config5_dense_g_mode_range_inverse_grid_both_builds(oracle, golden_dir, ell):
+    """BASELINE config 5's scans: tams with rot = 0.1, ell = 0, 2, 4, m = 0, Colloc4, the period-linear grid
+    rev_linspace(0.5, 1.0, 10^4) of `scan --inverse` (src/main.rs:816-817,1236-1238) over the dense g-mode range -- where
+    a discriminant at rounding level on a grid point is likeliest.  Same bars as config 4."""
+    model = rotating_tams(oracle, golden_dir)
+    o = oracle.Solver(model, ell, 0, "colloc4", model.field("r_coord"))
+    f = oracle.rev_linspace(0.5, 1.0, 10000)
+    ulp = oracle.relative_to_ulp(1e-8)
+    ref = o.scan_and_optimize(f, ulp, threads=16)
+    assert len(ref[0]) == {0: 0, 2: 9, 4: 19}[ell]   # (ell = 0 has no g modes: its scan comes back empty on both sides)
     check_parity_full(o, f, ulp, ref)
     check_fast_full(o, f, ulp, ref)
 

@@ -81,14 +81,17 @@ def test_noalloc_allocates_nothing_and_rejects_oversize(oracle, oracle_models):
     assert torch.cuda.mem_get_info()[0] == free0
     assert np.array_equal(bits(out), bits(ref))
     ffi.memory_cache_limit(16 << 30, 2 << 30)
-    # a forced segment length whose transfer matrices do not fit the scratch: 1000 x (1 + 3032/16 -> 192) x 128 B > 16 MiB
+    # a forced segment length whose transfer matrices do not fit the scratch (1000 x (1 + 3032/16 -> 192) x 128 B > 16 MiB):
+    # the plan is dropped and det_hex takes the batch -- the bits of storm_det_batch_device with "path" = 4
     big = torch.from_numpy(oracle.linspace(1.0, 20.0, 1000)).cuda()
-    big_out = torch.zeros_like(big)
+    big_out, big_ref = torch.zeros_like(big), torch.zeros_like(big)
     h.set_option("segments", 16)
     h.set_option("hex_min_n", 2000)
-    with pytest.raises(storm_amd.StormError) as e:
-        h.det_device_noalloc(big.data_ptr(), 1000, big_out.data_ptr())
-    assert e.value.code == -5
+    h.det_device_noalloc(big.data_ptr(), 1000, big_out.data_ptr())
+    h.set_option("path", 4)
+    h.det_device(big.data_ptr(), 1000, big_ref.data_ptr())
+    h.set_option("path", 0)
+    assert np.array_equal(bits(big_out), bits(big_ref))
     h.set_option("segments", 0)
     h.set_option("hex_min_n", 512)
     with pytest.raises(storm_amd.StormError) as e:      # beyond STORM_NOALLOC_MAX_N (rejected before anything is read)
@@ -96,3 +99,37 @@ def test_noalloc_allocates_nothing_and_rejects_oversize(oracle, oracle_models):
     assert e.value.code == -5
     h.det_device_noalloc(f.data_ptr(), 300, out.data_ptr())   # still usable
     assert np.array_equal(bits(out), bits(ref))
+
+
+def local_scale(d):
+    a = np.abs(d)
+    return np.maximum.reduce([np.roll(a, 1), a, np.roll(a, -1)])
+
+
+@pytest.mark.parametrize("arithmetic", [0, 1])
+def test_noalloc_follows_the_path_options_and_small_grids(oracle, oracle_models, arithmetic):
+    """The kernel choice is storm_det_batch_device's, options included; where that one would stage step matrices ("path" =
+    2; a small batch with no segment plan: parity build, or an FMA-build grid of fewer than 64 intervals) det_hex stands
+    in: the same bits in the parity build (every kernel path is bit-identical there), the FMA build's tolerance otherwise."""
+    import torch
+    import storm_amd
+    model = oracle_models("zams")
+    for grid in (model.field("r_coord"), model.field("r_coord")[::60]):
+        o = oracle.Solver(model, 2, 0, "colloc6", grid)
+        assert (o.n_int < 64) == (grid.size < 100)
+        h = storm_amd.HipSolver(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p)
+        h.set_option("arithmetic", arithmetic)
+        for n in (100, 777):
+            f = torch.from_numpy(oracle.linspace(1.0, 20.0, n)).cuda()
+            for path in (0, 1, 2, 3, 4):
+                h.set_option("path", path)
+                want, got = torch.zeros_like(f), torch.full_like(f, -1.0)
+                h.det_device(f.data_ptr(), n, want.data_ptr())
+                h.det_device_noalloc(f.data_ptr(), n, got.data_ptr())
+                w, g = want.cpu().numpy(), got.cpu().numpy()
+                staged = path == 2 or (path == 0 and n < 512 and (arithmetic == 0 or o.n_int < 64))
+                if arithmetic == 0 or not staged:
+                    assert np.array_equal(bits(got), bits(want)), (o.n_int, n, path)
+                else:
+                    assert np.all(np.abs(g - w) <= 1e-9 * local_scale(w)), (o.n_int, n, path)
+                    assert np.array_equal(np.signbit(g), np.signbit(w))
