@@ -198,21 +198,33 @@ def main():
 
     vec_buf = result_block(64 * (n_int + 1) * 4)  # reused from scan to scan
 
+    def roots_of(brackets):
+        """converged frequencies of a bracket list (dicts) or of a record array (storm_amd.distributed, column 4)"""
+        return brackets[:, 4].copy() if isinstance(brackets, np.ndarray) else np.array([b["root"] for b in brackets])
+
+    def indices_of(brackets):
+        return brackets[:, 6].astype(np.int64).tolist() if isinstance(brackets, np.ndarray) else [b["index"] for b in brackets]
+
     def eigenvectors(brackets):
         nonlocal vec_buf
-        if brackets:
+        if len(brackets):
             need = len(brackets) * (n_int + 1) * 4
             if vec_buf.size < need:
                 vec_buf = result_block(need)
-            h.eigenvector(np.array([b["root"] for b in brackets]), out=vec_buf)
+            h.eigenvector(roots_of(brackets), out=vec_buf)
 
-    def one_scan():
+    phase_s = {}
+
+    def one_scan(timings=None):
         """StormState::scan on this rank's share; returns the global bracket list."""
-        if world == 1:
+        if world == 1 and timings is None:
             res, _, _ = h.scan_and_optimize(freqs, ulp, cap=8192, want_dets=False)  # (the reference returns brackets only)
             eigenvectors(res)
             return res
-        res, _, _ = D.strong_scan_and_optimize(h, freqs, ulp, device=coll_device, after_refine=eigenvectors)
+        # N > 1 (and the phase-timing pass at N = 1): the two halves as separate calls with the gathers in between;
+        # brackets travel as record arrays (no per-bracket Python inside the step)
+        res, _, _ = D.strong_scan_and_optimize(h, freqs, ulp, device=coll_device, after_refine=eigenvectors,
+                                               timings=timings, records=True)
         return res
 
     # Before anything is timed: the FMA build must find the parity build's brackets, index for index, on the full grid.
@@ -220,10 +232,10 @@ def main():
     for arith, name in ((0, "parity"), (1, "fast")):
         h.set_option("arithmetic", arith)
         found[name] = one_scan()
-    idx_p, idx_f = [b["index"] for b in found["parity"]], [b["index"] for b in found["fast"]]
+    idx_p, idx_f = indices_of(found["parity"]), indices_of(found["fast"])
     if idx_p != idx_f:
         raise SystemExit(f"fast arithmetic changed the bracket index list on the full grid: {idx_p} vs {idx_f}")
-    rp, rf = np.array([b["root"] for b in found["parity"]]), np.array([b["root"] for b in found["fast"]])
+    rp, rf = roots_of(found["parity"]), roots_of(found["fast"])
     root_diff = float(np.max(np.abs(rf - rp) / np.abs(rp))) if rp.size else 0.0
     if root_diff > 1e-10:
         raise SystemExit(f"fast arithmetic moved a root by {root_diff:.3e} relative (> 1e-10)")
@@ -317,12 +329,73 @@ def main():
     other_steps = max(1, min(args.steps, 5))
     other = measure(1 - main_arith, other_steps, 1)
     roof = {a: (roofline_of(a) if rank == 0 else None) for a in (0, 1)}
+
+    def phase_times(steps=5):
+        """Where a step goes, per rank: the scan of the rank's slice, the gather of the unrefined brackets, the refinement of
+        the brackets dealt to the rank, their eigenvectors, the gather of the refined records (host clock around each
+        phase inside strong_scan_and_optimize, every phase ends synchronised).  At N = 1 the two gathers do not exist and
+        the step is the two-call form of the scan (storm_scan_brackets, storm_optimize_brackets), not the one-call form
+        `value` is measured on.  Returns rank 0's figures and the maximum over the ranks, ms per step."""
+        h.set_option("arithmetic", main_arith)
+        one_scan(timings={})
+        t = {}
+        sync()
+        for _ in range(steps):
+            one_scan(timings=t)
+        sync()
+        mine_ms = [t.get(k, 0.0) / steps * 1e3 for k in D.PHASES]
+        if world > 1:
+            tt = torch.tensor(mine_ms, dtype=torch.float64, device=coll_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            worst = tt.tolist()
+        else:
+            worst = mine_ms
+        names = ["slice_scan", "gather_found", "refine", "eigenvectors", "gather_refined"]
+        return {"steps": steps, "arithmetic": "fast" if main_arith else "parity", "unit": "ms per step",
+                "frequencies_in_this_ranks_slice": int(len(mine)),
+                "rank0": {k: round(v, 4) for k, v in zip(names, mine_ms)},
+                "max_over_ranks": {k: round(v, 4) for k, v in zip(names, worst)},
+                "sum_of_max": round(sum(worst), 4)}
+
+    phases = phase_times()
+
+    def multi_in_library(steps=5):
+        """The same strong-scaled scan through storm_multi_* (include/storm_hip.h): ONE process, one solver and one host
+        thread per device, gathers in host memory, no collective library -- the form the Rust host would call.  Run by rank
+        0 over the N devices of the job while the other ranks wait (their processes hold no kernels then)."""
+        if torch.cuda.device_count() < world:
+            return {"skipped": f"{torch.cuda.device_count()} device(s) visible to rank 0, {world} needed"}
+        devices = list(range(world)) if world > 1 else [local_rank]
+        ms = host.MultiSolver(model, 2, 0, "colloc4", grid, devices)
+        ms.hip.set_option("arithmetic", main_arith)
+
+        def step():
+            res, _, _ = ms.hip.scan_and_optimize(freqs, ulp, cap=8192, want_dets=False)
+            if res:
+                ms.hip.eigenvector(roots_of(res), out=vec_buf)
+            return res
+
+        step()
+        ms.hip.stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        dt = time.perf_counter() - t0
+        st = ms.hip.stats()
+        torch.cuda.set_device(local_rank)
+        return {"devices": devices, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "modes_per_step": len(res),
+                "value": st["det_evals"] * n_int / dt, "unit": "freq*interval evals/s",
+                "bracket_indices_equal_headline": indices_of(res) == idx_f}
+
+    multi = multi_in_library() if rank == 0 else None
+    if world > 1:
+        dist.barrier()
     h.set_option("arithmetic", 0)
 
     def eigen_roofline():
         """The eigenvector kernels of the headline's modes against their HBM roofline (per interval and
         mode 128 B step matrix in, 176 B factors out and in again, 32 B eigenvector out)."""
-        roots = np.array([b["root"] for b in found["parity"]])
+        roots = roots_of(found["parity"])
         if not roots.size:
             return None
         h.eigenvector(roots)
@@ -359,6 +432,7 @@ def main():
             "det_evals": res["det_evals"], "refine_evals": res["refine"],
             "refine_rounds_per_scan": res["rounds_per_scan"], "launches_per_scan": res["launches_per_scan"],
             "fast_vs_parity": identity, "kernels": res["kernels"], "roofline": roof[main_arith],
+            "phases": phases, "multi_in_library": multi,
             f"{name_other}_arithmetic": {
                 "value": other["det_evals"] * n_int / other["elapsed"], "unit": "freq*interval evals/s",
                 "steps": other_steps, "ms_per_step": other["elapsed"] / other_steps * 1e3,

@@ -95,6 +95,24 @@ void* storm_host_solver_new(void* m, uint64_t ell, int64_t mm, int scheme, const
   return s;
 }
 void storm_host_solver_free(void* s) { delete static_cast<ErasedSolver*>(s); }
+
+// MultiSolver: the same solver over several devices from this process (storm_multi_*)
+void* storm_host_multi_new(void* m, uint64_t ell, int64_t mm, int scheme, const double* grid, size_t ngrid,
+                           const int* devices, size_t n_dev) {
+  HostModel* h = static_cast<HostModel*>(m);
+  MultiSolver* s = nullptr;
+  if (guarded([&] {
+        if (scheme < 0 || scheme > 7) throw std::runtime_error("unknown difference scheme");
+        auto cm = h->continuous();
+        s = new MultiSolver(*cm, Rotating1D::make(ell, mm), DifferenceSchemes(scheme),
+                            std::vector<double>(grid, grid + ngrid), std::vector<int>(devices, devices + n_dev));
+      })) return nullptr;
+  return s;
+}
+void storm_host_multi_free(void* s) { delete static_cast<MultiSolver*>(s); }
+size_t storm_host_multi_len(void* s) { return static_cast<MultiSolver*>(s)->len(); }
+size_t storm_host_multi_points(void* s) { return static_cast<MultiSolver*>(s)->points(); }
+void* storm_host_multi_handle(void* s) { return static_cast<MultiSolver*>(s)->handle(); }
 size_t storm_host_solver_len(void* s) { return static_cast<ErasedSolver*>(s)->len(); }
 void* storm_host_solver_handle(void* s) { return static_cast<ErasedSolver*>(s)->handle(); }
 

@@ -321,6 +321,35 @@ ErasedSolver::ErasedSolver(const ContinuousModel& model, Rotating1D system, Diff
 
 ErasedSolver::~ErasedSolver() { storm_solver_destroy(h_); }
 
+MultiSolver::MultiSolver(const ContinuousModel& model, Rotating1D system, DifferenceSchemes scheme,
+                         const std::vector<double>& grid, const std::vector<int>& devices) {
+  const SystemArrays arrays(model, scheme, grid);
+  const storm_system_desc desc = arrays.desc(system, scheme);
+  const int rc = storm_multi_create(&desc, devices.data(), devices.size(), &h_);
+  if (rc != STORM_OK) raise_abi("storm_multi_create", rc);
+  n_int_ = arrays.steps;
+  p_ = arrays.p;
+}
+MultiSolver::~MultiSolver() { storm_multi_destroy(h_); }
+std::vector<BracketResult> MultiSolver::scan_and_optimize(const std::vector<double>& grid, Precision precision,
+                                                          bool* had_invalid) const {
+  std::vector<storm_bracket> raw(grid.size() ? grid.size() : 1);
+  size_t n_out = 0;
+  int invalid = 0;
+  const int rc = storm_multi_scan_and_optimize(h_, grid.data(), grid.size(), precision.as_ulp(), raw.data(), raw.size(),
+                                               &n_out, &invalid, nullptr, nullptr);
+  if (rc != STORM_OK) raise_abi("storm_multi_scan_and_optimize", rc);
+  if (had_invalid) *had_invalid = invalid != 0;
+  std::vector<BracketResult> out(n_out);
+  for (size_t k = 0; k < n_out; ++k)
+    out[k] = BracketResult{Point{raw[k].lo_x, raw[k].lo_f}, Point{raw[k].hi_x, raw[k].hi_f}, raw[k].root, raw[k].evals};
+  return out;
+}
+void MultiSolver::eigenvectors_into(const double* freqs, size_t n, double* out) const {
+  const int rc = storm_multi_eigenvector_batch(h_, freqs, n, nullptr, out);
+  if (rc != STORM_OK) raise_abi("storm_multi_eigenvector_batch", rc);
+}
+
 double ErasedSolver::det(double freq) const {
   double out = 0.;
   const int rc = storm_det_batch(h_, &freq, 1, &out);

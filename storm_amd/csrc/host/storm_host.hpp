@@ -142,6 +142,28 @@ class ErasedSolver {  // dynamic_interface.rs:60-160
   size_t n_int_ = 0;
 };
 
+// ErasedSolver over several GPUs of the node from this process (storm_multi_*, include/storm_hip.h): the same two calls,
+// the scan's frequency grid cut into one contiguous slice per listed device, brackets and modes dealt out cyclically.
+// Results are bit-identical to ErasedSolver's.  This is the form the Rust host would take for `scan`.
+class MultiSolver {
+ public:
+  MultiSolver(const ContinuousModel& model, Rotating1D system, DifferenceSchemes scheme,
+              const std::vector<double>& solver_grid, const std::vector<int>& devices);
+  ~MultiSolver();
+  MultiSolver(const MultiSolver&) = delete;
+  MultiSolver& operator=(const MultiSolver&) = delete;
+  std::vector<BracketResult> scan_and_optimize(const std::vector<double>& freq_grid, Precision precision,
+                                               bool* had_invalid_numbers = nullptr) const;
+  void eigenvectors_into(const double* freqs, size_t n, double* out) const;
+  size_t len() const { return n_int_; }
+  size_t points() const { return p_; }
+  storm_multi* handle() const { return h_; }
+
+ private:
+  storm_multi* h_ = nullptr;
+  size_t n_int_ = 0, p_ = 0;
+};
+
 struct Solution {  // main.rs:1225-1230
   BracketResult bracket;
   std::vector<double> eigenvector;

@@ -732,7 +732,7 @@ void steps_release(storm_solver* s, hipStream_t st) {
 // Segment-parallel evaluation (scheme_kernels.hpp, "Segment-parallel kernels"): how the interval axis is cut for a batch
 // of n frequencies.  n_seg == 0: not applicable.
 struct SegPlan { int n_seg = 0, seg_len = 0; };
-SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len, size_t min_segments = 0) {
+SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len, size_t min_segments = 0, bool serial_boundaries = false) {
   SegPlan p;
   const size_t n_int = s->sys.n_int;
   if (s->arith != 1 || s->segments < 0 || n == 0 || n_int < 64) return p;  // the parity build keeps the reference's association
@@ -743,6 +743,15 @@ SegPlan plan_segments(const storm_solver* s, size_t n, size_t max_len, size_t mi
     const size_t target_groups = 4096;  // 16-lane groups in flight: one wave per SIMD
     const size_t want = std::max<size_t>({size_t(1), target_groups / n, min_segments});
     len = ((n_int + want - 1) / want + 15) / 16 * 16;
+    if (serial_boundaries) {
+      // Eigenvectors: the boundary system is eliminated by ONE wave per mode, ~0.9 us per boundary (eigen_forward +
+      // eigen_backsub), while a segment costs seg_product + seg_fill ~0.33 us per interval of its length as long as the
+      // groups fit the chip.  a n_int / len + b len is least at len = sqrt(a n_int / b) = sqrt(2.7 n_int): 160-176
+      // intervals for 10^4.  Filling the chip (the rule above) asks for much shorter segments when there are few modes
+      // (3 modes: 32 intervals, 316 boundaries, 0.29 ms; balanced: 0.13 ms), so take the longer of the two.
+      const size_t balanced = (size_t(std::sqrt(2.7 * double(n_int))) + 15) / 16 * 16;
+      len = std::max(len, balanced);
+    }
     len = std::min(std::max<size_t>(len, 32), max_len);
   }
   size_t n_seg = (1 + (n_int - 1 + len - 1) / len + 3) / 4 * 4;  // the first interval is a segment of its own
@@ -1107,7 +1116,7 @@ void eigen_segments(storm_solver* s, const SegPlan& plan, size_t m) {
 // Eigenvectors of m host frequencies into s->d_vec (and discriminants into s->d_det), left on the device.
 void eigen_chunk(storm_solver* s, const double* freq, size_t m) {
   hip_check(hipMemcpyAsync(s->d_freq.p, freq, m * sizeof(double), hipMemcpyHostToDevice, s->stream), "freq H2D");
-  const SegPlan plan = plan_segments(s, m, 256);
+  const SegPlan plan = plan_segments(s, m, 256, 0, true);
   if (plan.n_seg) {
     s->h_freq_last = freq;
     eigen_segments(s, plan, m);

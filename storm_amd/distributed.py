@@ -43,18 +43,68 @@ def unpack(rec):
 GATHER_CAP = 64  # bracket records per rank that fit the first exchange (a scan finds a few dozen modes in all)
 
 
+class _Exchange:
+    """The buffers of one all_gather shape, allocated once per (device, shape) and reused from scan to scan: the send and
+    receive tensors on the collective's device and, for a GPU, pinned host mirrors, so an exchange is one async H2D copy,
+    the collective and one async D2H copy on torch's current stream, then one stream synchronisation."""
+
+    def __init__(self, device, world, shape):
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.h_send = torch.zeros(shape, dtype=torch.float64, pin_memory=self.on_gpu)
+        self.h_recv = torch.zeros((world,) + tuple(shape), dtype=torch.float64, pin_memory=self.on_gpu)
+        self.send = torch.zeros(shape, dtype=torch.float64, device=self.device) if self.on_gpu else self.h_send
+        self.recv = torch.zeros((world,) + tuple(shape), dtype=torch.float64, device=self.device) if self.on_gpu else self.h_recv
+        self.parts = None
+        self.send_np, self.recv_np = self.h_send.numpy(), self.h_recv.numpy()
+
+    def run(self):
+        """all_gather of send_np (filled by the caller) -> recv_np [world, *shape]"""
+        if self.on_gpu:
+            self.send.copy_(self.h_send, non_blocking=True)
+        if _single_tensor_form():
+            dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            if self.parts is None:
+                self.parts = list(self.recv.unbind(0))   # views into recv: the list form writes in place
+            dist.all_gather(self.parts, self.send)
+        if self.on_gpu:
+            self.h_recv.copy_(self.recv, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        return self.recv_np
+
+
+_EXCHANGES = {}
+_FORM = {}
+
+
+def _single_tensor_form():
+    """Which all_gather the process group's backend gets, decided ONCE per process group before the first collective: the
+    single-tensor form on RCCL (`nccl`), the list form elsewhere (gloo in the CPU tests).  No try/except around a
+    collective: an error inside one is a real error, and answering it with a different collective would leave the ranks in
+    mismatched calls."""
+    key = dist.get_backend()
+    if key not in _FORM:
+        _FORM[key] = key == "nccl" and hasattr(dist, "all_gather_into_tensor")
+    return _FORM[key]
+
+
+def _exchange(device, shape):
+    key = (str(device), dist.get_world_size(), tuple(shape), id(dist.group.WORLD))
+    ex = _EXCHANGES.get(key)
+    if ex is None:
+        if len(_EXCHANGES) > 16:   # (shapes other than the two standing ones are rare: do not keep them all)
+            _EXCHANGES.clear()
+        ex = _EXCHANGES[key] = _Exchange(device, dist.get_world_size(), shape)
+    return ex
+
+
 def _all_gather_rows(buf, device):
-    """all_gather of one equally shaped float64 array per rank -> array [world, *buf.shape] on the host."""
-    world = dist.get_world_size()
-    t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=device)
-    try:
-        dist.all_gather_into_tensor(out, t)
-    except (RuntimeError, NotImplementedError, AttributeError):  # a backend without the single-tensor form
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
-        out = torch.stack(parts)
-    return out.cpu().numpy()
+    """all_gather of one equally shaped float64 array per rank -> array [world, *buf.shape] on the host (a view of the
+    exchange's receive buffer: valid until the next exchange of the same shape)."""
+    ex = _exchange(device, buf.shape)
+    ex.send_np[...] = buf
+    return ex.run()
 
 
 def gather_brackets(local_records, invalid, device):
@@ -63,11 +113,12 @@ def gather_brackets(local_records, invalid, device):
     ONE collective in the usual case: every rank sends GATHER_CAP padded records behind a header row (count, invalid
     flag); only if some rank found more is a second exchange made, sized by the largest count."""
     n = local_records.shape[0]
-    buf = np.zeros((GATHER_CAP + 1, RECORD))
+    ex = _exchange(device, (GATHER_CAP + 1, RECORD))
+    buf = ex.send_np
     buf[0, 0], buf[0, 1] = float(n), 1.0 if invalid else 0.0
     if n:
         buf[1:1 + min(n, GATHER_CAP)] = local_records[:GATHER_CAP]
-    got = _all_gather_rows(buf, device)
+    got = ex.run()
     counts = got[:, 0, 0].astype(np.int64)
     any_invalid = bool(got[:, 0, 1].any())
     if counts.max(initial=0) > GATHER_CAP:
@@ -103,44 +154,84 @@ def deal(n_brackets, world, rank):
     return list(range(rank, n_brackets, world))
 
 
-def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None):
+PHASES = ("slice_scan", "gather_found", "refine", "after_refine", "gather_refined")
+
+
+def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None, timings=None, records=False):
     """scan_and_optimize of ONE frequency grid split over the ranks of the default process group (strong scaling).
 
     Every rank evaluates a contiguous slice (+1 halo point) and finds its sign swaps (`solver.scan_brackets`); the
-    unrefined brackets are gathered (all_gather of counts, all_gather of padded records), dealt out cyclically, refined
+    unrefined brackets are gathered (one all_gather of padded records behind a header row), dealt out cyclically, refined
     where they were dealt (`solver.optimize_brackets`), and the refined records are gathered again (one all_gather: the
     deal fixes every rank's count).  `after_refine(my_brackets)` runs between refinement and the last gather (the
-    eigenvectors of this rank's modes).  Returns (all brackets in ascending order, any_invalid, this rank's brackets).
+    eigenvectors of this rank's modes).  Returns (all brackets in ascending order, any_invalid, this rank's brackets) --
+    lists of dicts, or with `records` the [n, RECORD] arrays themselves (no per-bracket Python at all).
+    `timings`: a dict that receives this rank's seconds per phase (PHASES), accumulated over calls.
 
     `solver` needs .scan_brackets(freqs) -> (brackets with 'index', dets, invalid) and
-    .optimize_brackets(brackets, ulp) -> brackets."""
+    .optimize_brackets(brackets, ulp) -> brackets; if it has .scan_brackets_records / .optimize_records (ffi.HipSolver)
+    those are used instead and the records go from the C struct array to the exchange buffer as numpy columns."""
+    import time
     freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+    fast = hasattr(solver, "scan_brackets_records") and hasattr(solver, "optimize_records")
+    clock = [time.perf_counter()]
+
+    def lap(phase):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[phase] = timings.get(phase, 0.0) + now - clock[0]
+            clock[0] = now
+
+    def scan(f, offset):
+        if len(f) < 2:
+            return np.zeros((0, RECORD)), False
+        if fast:
+            return solver.scan_brackets_records(f, offset)
+        found, _, inv = solver.scan_brackets(f)
+        return pack(found, offset), inv
+
+    def refine(rec):
+        if not rec.shape[0]:
+            return rec
+        if fast:
+            return solver.optimize_records(rec, ulp)
+        return pack(solver.optimize_brackets(unpack(rec), ulp), 0)
+
+    give = (lambda rec: rec) if records else unpack
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        res, _, inv = solver.scan_brackets(freqs)
-        res = solver.optimize_brackets(res, ulp)
+        rec, inv = scan(freqs, 0)
+        lap("slice_scan")
+        rec = refine(rec)
+        lap("refine")
+        out = give(rec)
         if after_refine is not None:
-            after_refine(res)
-        return res, inv, res
+            after_refine(out)
+        lap("after_refine")
+        return out, inv, out
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, mine = local_slice(freqs, world, rank)
-    found, _, inv = solver.scan_brackets(mine) if len(mine) > 1 else ([], None, False)
-    rec, any_inv = gather_brackets(pack(found, lo), inv, device)
-    share = deal(rec.shape[0], world, rank)
-    my = solver.optimize_brackets(unpack(rec[share]), ulp) if share else []
+    found, inv = scan(mine, lo)
+    lap("slice_scan")
+    rec, any_inv = gather_brackets(found, inv, device)
+    lap("gather_found")
+    n_all = rec.shape[0]
+    my = refine(rec[rank::world])          # the cyclic deal (deal())
+    lap("refine")
+    my_out = give(my)
     if after_refine is not None:
-        after_refine(my)
+        after_refine(my_out)
+    lap("after_refine")
     # second exchange: every rank's count follows from the deal, so one all_gather of padded records is enough
-    cap = max(1, -(-rec.shape[0] // world))
-    buf = np.zeros((cap, RECORD))
-    if my:
-        buf[:len(my)] = pack(my, 0)
-    got = _all_gather_rows(buf, device)
-    out = np.zeros((rec.shape[0], RECORD))
+    cap = max(1, -(-n_all // world))
+    ex = _exchange(device, (cap, RECORD))
+    ex.send_np[:my.shape[0]] = my
+    got = ex.run()
+    out = np.empty((n_all, RECORD))
     for r in range(world):
-        idx = deal(rec.shape[0], world, r)
-        if idx:
-            out[idx] = got[r, :len(idx)]
-    return unpack(out), any_inv, my
+        cnt = len(range(r, n_all, world))
+        out[r::world] = got[r, :cnt]
+    lap("gather_refined")
+    return give(out), any_inv, my_out
 
 
 # ---- rotation sweeps (storm_sweep): systems are independent, so they are dealt out whole ----

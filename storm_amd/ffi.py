@@ -26,6 +26,10 @@ class Bracket(C.Structure):
                 ("root", C.c_double), ("evals", C.c_uint64)]
 
 
+BRACKET_DTYPE = np.dtype([("lo_x", "<f8"), ("lo_f", "<f8"), ("hi_x", "<f8"), ("hi_f", "<f8"), ("root", "<f8"), ("evals", "<u8")])
+assert BRACKET_DTYPE.itemsize == C.sizeof(Bracket)
+
+
 class SystemDesc(C.Structure):
     _fields_ = [("scheme", C.c_int32), ("ell", C.c_uint64), ("m", C.c_int64), ("n_int", C.c_size_t),
                 ("p", C.c_size_t), ("u", _dp), ("v_gamma", _dp), ("a_star", _dp), ("c1", _dp), ("rot", _dp),
@@ -303,6 +307,41 @@ class HipSolver:
                     index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
         return res, dets, bool(inv.value)
 
+    # ---- the same two calls on record arrays (storm_amd.distributed: rows of RECORD float64 columns lo_x, lo_f, hi_x, hi_f,
+    # root, evals, global index), packed and unpacked through numpy views of the C struct array: no per-bracket Python
+    def scan_brackets_records(self, freqs, offset=0, cap=None):
+        """storm_scan_brackets -> (records [n, 7], invalid); `offset` is added to the bracket indices (a slice's position in
+        the whole grid).  The discriminants of the grid stay on the device."""
+        f = _f64(freqs)
+        cap = max(1, f.size) if cap is None else cap
+        out = (Bracket * max(cap, 1))()
+        idx = (C.c_uint64 * max(cap, 1))()
+        n_out, inv = C.c_size_t(0), C.c_int(0)
+        _check(load_library().storm_scan_brackets(self._h, _p(f), f.size, out, cap, C.byref(n_out), C.byref(inv), None, idx))
+        n = n_out.value
+        rec = np.empty((n, 7))
+        b = np.frombuffer(out, dtype=BRACKET_DTYPE, count=n)
+        for k, name in enumerate(("lo_x", "lo_f", "hi_x", "hi_f", "root", "evals")):
+            rec[:, k] = b[name]
+        rec[:, 6] = np.frombuffer(idx, dtype=np.uint64, count=n) + np.uint64(offset)
+        return rec, bool(inv.value)
+
+    def optimize_records(self, rec, ulp):
+        """storm_optimize_brackets on records [n, 7] (columns 0..3 in; 0..5 out, column 6 kept) -> new array"""
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        n = rec.shape[0]
+        arr = (Bracket * max(n, 1))()
+        b = np.frombuffer(arr, dtype=BRACKET_DTYPE, count=n)
+        for k, name in enumerate(("lo_x", "lo_f", "hi_x", "hi_f")):
+            b[name] = rec[:, k]
+        b["root"] = np.nan
+        b["evals"] = 0
+        _check(load_library().storm_optimize_brackets(self._h, arr, n, ulp))
+        out = rec.copy()
+        for k, name in enumerate(("lo_x", "lo_f", "hi_x", "hi_f", "root", "evals")):
+            out[:, k] = b[name]
+        return out
+
     def optimize_brackets(self, brackets, ulp):
         """storm_optimize_brackets on a list of dicts with lo_x, lo_f, hi_x, hi_f (other keys are kept)."""
         n = len(brackets)
@@ -366,11 +405,22 @@ class HipMulti:
         _check(L.storm_multi_create(C.byref(d), devs, len(devices), C.byref(h)))
         self._h = h
         self.n_int, self.p, self.scheme, self.n_dev = n_int, p, scheme, len(devices)
+        self._owner = None
+
+    @classmethod
+    def borrow(cls, raw_handle, n_int, p, scheme, n_dev, owner=None):
+        """A view of a storm_multi owned by someone else (storm_amd.host.MultiSolver)."""
+        load_library()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(raw_handle)
+        self.n_int, self.p, self.scheme, self.n_dev = n_int, p, scheme, n_dev
+        self._owner = owner if owner is not None else True
+        return self
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owner", None) is None:
             load_library().storm_multi_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -386,23 +436,24 @@ class HipMulti:
         _check(load_library().storm_multi_stats(self._h, C.byref(s), 1 if reset else 0))
         return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
 
-    def scan_and_optimize(self, freqs, ulp, cap=None):
+    def scan_and_optimize(self, freqs, ulp, cap=None, want_dets=True):
         f = _f64(freqs)
         cap = max(1, f.size) if cap is None else cap
         out = (Bracket * max(cap, 1))()
         idx = (C.c_uint64 * max(cap, 1))()
-        dets = np.empty(f.size)
+        dets = np.empty(f.size) if want_dets else None
         n_out, inv = C.c_size_t(0), C.c_int(0)
         _check(load_library().storm_multi_scan_and_optimize(self._h, _p(f), f.size, ulp, out, cap, C.byref(n_out),
-                                                            C.byref(inv), _p(dets), idx))
+                                                            C.byref(inv), _p(dets) if want_dets else None, idx))
         res = [dict(lo_x=b.lo_x, lo_f=b.lo_f, hi_x=b.hi_x, hi_f=b.hi_f, root=b.root, evals=int(b.evals),
                     index=int(idx[i])) for i, b in enumerate(out[:n_out.value])]
         return res, dets, bool(inv.value)
 
-    def eigenvector(self, freqs):
+    def eigenvector(self, freqs, out=None):
         f = _f64(np.atleast_1d(freqs))
         dets = np.empty(f.size)
-        vec = np.empty((f.size, (self.n_int + 1) * 4))
+        length = (self.n_int + 1) * 4
+        vec = np.empty((f.size, length)) if out is None else out.reshape(-1)[:f.size * length].reshape(f.size, length)
         _check(load_library().storm_multi_eigenvector_batch(self._h, _p(f), f.size, _p(dets), _p(vec)))
         return dets, vec
 

@@ -51,6 +51,15 @@ def load_host_library():
     L.storm_host_solver_handle.restype = C.c_void_p
     L.storm_host_solver_handle.argtypes = [C.c_void_p]
     L.storm_host_solver_det.argtypes = [C.c_void_p, _dp, C.c_size_t, _dp]
+    L.storm_host_multi_new.restype = C.c_void_p
+    L.storm_host_multi_new.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_int), C.c_size_t]
+    L.storm_host_multi_free.argtypes = [C.c_void_p]
+    L.storm_host_multi_len.restype = C.c_size_t
+    L.storm_host_multi_len.argtypes = [C.c_void_p]
+    L.storm_host_multi_points.restype = C.c_size_t
+    L.storm_host_multi_points.argtypes = [C.c_void_p]
+    L.storm_host_multi_handle.restype = C.c_void_p
+    L.storm_host_multi_handle.argtypes = [C.c_void_p]
     L.storm_host_solver_scan_and_optimize.argtypes = [C.c_void_p, _dp, C.c_size_t, C.c_int, C.c_uint64, C.c_double,
                                                       C.POINTER(Bracket), C.c_size_t, C.POINTER(C.c_size_t),
                                                       C.POINTER(C.c_int)]
@@ -270,6 +279,32 @@ class ErasedSolver:
     def __del__(self):
         try:
             load_host_library().storm_host_solver_free(self._h)
+        except Exception:
+            pass
+
+
+class MultiSolver:
+    """storm_host::MultiSolver: ErasedSolver over several devices of the node from this process (storm_multi_*);
+    `.hip` is the ffi.HipMulti view of its handle (scan_and_optimize, eigenvector, set_option, stats)."""
+
+    def __init__(self, model, ell, m, scheme, solver_grid, devices):
+        if isinstance(scheme, str):
+            scheme = SCHEMES.index(scheme)
+        g = _f64(solver_grid)
+        devs = (C.c_int * len(devices))(*devices)
+        L = load_host_library()
+        h = L.storm_host_multi_new(model._h, ell, m, scheme, _p(g), g.size, devs, len(devices))
+        if not h:
+            raise _err()
+        self._h = C.c_void_p(h)
+        self._model = model
+        self.n_int = L.storm_host_multi_len(self._h)
+        self.hip = ffi.HipMulti.borrow(L.storm_host_multi_handle(self._h), self.n_int, L.storm_host_multi_points(self._h),
+                                       scheme, len(devices), owner=self)
+
+    def __del__(self):
+        try:
+            load_host_library().storm_host_multi_free(self._h)
         except Exception:
             pass
 

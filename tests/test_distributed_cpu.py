@@ -114,6 +114,58 @@ def test_strong_scaling_scan_deals_brackets_and_matches_single_process(tmp_path,
     assert sorted(dealt) == [b["index"] for b in ref]  # every bracket refined by exactly one rank
 
 
+class _OracleRecords(_OracleHalves):
+    """... and for ffi.HipSolver.scan_brackets_records / optimize_records (the array form the RCCL path takes)."""
+
+    def scan_brackets_records(self, freqs, offset=0):
+        from storm_amd import distributed as D
+        res, _, inv = self.scan_brackets(freqs)
+        return D.pack(res, offset), inv
+
+    def optimize_records(self, rec, ulp):
+        from storm_amd import distributed as D
+        return D.pack(self.optimize_brackets(D.unpack(rec), ulp), 0)
+
+
+def _records_worker(rank, world, port, n_freq, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import storm_ref
+    from storm_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = storm_ref.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_zams.npz"))
+        solver = _OracleRecords(storm_ref.Solver(model, 1, 0, "colloc2", model.field("r_coord")))
+        freqs = storm_ref.linspace(1.0, 25.0, n_freq)
+        timings = {}
+        for _ in range(2):   # twice: the second scan reuses the exchange buffers of the first
+            seen = []
+            rec, inv, mine = D.strong_scan_and_optimize(solver, freqs, 1, device="cpu", after_refine=seen.append,
+                                                        timings=timings, records=True)
+            assert isinstance(rec, np.ndarray) and rec.shape[1] == D.RECORD and seen[0] is mine
+        assert set(timings) == set(D.PHASES) and all(v >= 0.0 for v in timings.values())
+        np.save(os.path.join(out_dir, f"rec{rank}.npy"), rec)
+        np.save(os.path.join(out_dir, f"recmine{rank}.npy"), mine)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_record_arrays_and_phase_timings(tmp_path, oracle, oracle_models):
+    from storm_amd import distributed as D
+    world, n_freq = 2, 80
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_records_worker, args=(world, port, n_freq, str(tmp_path)), nprocs=world, join=True)
+    model = oracle_models("zams")
+    solver = oracle.Solver(model, 1, 0, "colloc2", model.field("r_coord"))
+    ref, _, _ = solver.scan_and_optimize(oracle.linspace(1.0, 25.0, n_freq), 1, threads=8)
+    ref_rec = D.pack(ref, 0)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rec{r}.npy").view(np.uint64), ref_rec.view(np.uint64)), f"rank {r}"
+        assert np.array_equal(np.load(tmp_path / f"recmine{r}.npy").view(np.uint64), ref_rec[r::world].view(np.uint64))
+
+
 def test_shard_bounds_cover_every_pair_once():
     from storm_amd import distributed as D
     for n in (0, 1, 2, 7, 64, 100001):
