@@ -19,6 +19,10 @@
 #include <vector>
 
 #include "common_kernels.hpp"
+#include "hostlogic/brackets.hpp"
+#include "hostlogic/failure.hpp"
+#include "hostlogic/memory_cache.hpp"
+#include "hostlogic/multi.hpp"
 #include "postprocess.hpp"
 #include "types.hpp"
 
@@ -58,332 +62,41 @@ static const launch_fn g_hexinfo[2][kNumSchemes] = STORM_TABLE(hexinfo);
 
 static thread_local std::string g_error;
 
-struct Failure {
-  int code;
-  std::string msg;
-};
-[[noreturn]] static void fail(int code, const std::string& msg) { throw Failure{code, msg}; }
+// (Failure / fail(): hostlogic/failure.hpp)
 static void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) fail(STORM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// Process-wide cache of device buffers, pinned host buffers and streams.  hipFree / hipHostFree / hipStreamDestroy
-// synchronise the whole device and hipMalloc / hipHostMalloc cost 0.1-1 ms on an idle device (far more on a busy one, see Arena): with one handle per small scan (the
-// rotation sweeps of the reference's batch scripts run thousands of 100-300 frequency scans, each on its own system)
-// they serialised concurrent scans (scripts/many_scans_bench.py).  Blocks are kept by size and handed to the next
-// handle that asks; only what exceeds the cache limit goes back to the runtime.  A block is given back only after
-// the stream that used it has been synchronised (see DevBuf::reserve and the destroy functions).
-// A slab of device memory that large blocks are carved from.  With kernels of other handles in flight a hipMalloc took
-// 30 ms - 5.5 s on the box whatever its size (the 1001-rate batch of tools/storm_batch with four groups in flight: a run
-// that met a dozen of them took 3-7 s instead of 2.1 s; this is also the multi-second stall DESIGN.md section 8 recorded
-// in round 1) and a hipFree waits for the whole device, so blocks of 64 MiB and more never reach the runtime one by
-// one: the first request allocates a slab while the device is still idle and later ones grow the set by doubling.
-struct Arena {
-  char* base = nullptr;
-  size_t size = 0, free_bytes = 0;
-  std::map<size_t, size_t> holes;  // offset -> length, neighbours coalesced
-  bool contains(const void* p) const { return p >= base && p < base + size; }
-  void* carve(size_t bytes) {  // best fit
-    auto best = holes.end();
-    for (auto it = holes.begin(); it != holes.end(); ++it)
-      if (it->second >= bytes && (best == holes.end() || it->second < best->second)) best = it;
-    if (best == holes.end()) return nullptr;
-    const size_t off = best->first, len = best->second;
-    holes.erase(best);
-    if (len > bytes) holes.emplace(off + bytes, len - bytes);
-    free_bytes -= bytes;
-    return base + off;
-  }
-  void put_back(void* p, size_t bytes) {
-    size_t off = size_t(static_cast<char*>(p) - base), len = bytes;
-    auto next = holes.lower_bound(off);
-    if (next != holes.begin()) {
-      auto prev = std::prev(next);
-      if (prev->first + prev->second == off) { off = prev->first; len += prev->second; holes.erase(prev); }
-    }
-    if (next != holes.end() && off + len == next->first) { len += next->second; holes.erase(next); }
-    holes.emplace(off, len);
-    free_bytes += bytes;
-  }
-};
-
-class MemoryCache {
- public:
-  static MemoryCache& get() { static MemoryCache m; return m; }
-  static constexpr size_t kMedium = size_t(1) << 20;  // blocks from this size on live in arenas ...
-  static constexpr size_t kLarge = size_t(64) << 20;  // ... those from this size on in slabs of their own
-  static size_t size_class(size_t bytes) {
-    if (bytes <= 256) return 256;
-    if (bytes < kMedium) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
-    if (bytes < kLarge) return (bytes + kMedium - 1) >> 20 << 20;
-    // large blocks: eight classes per power of two, so that the slightly different sizes successive handles ask for
-    // (a sweep's staging follows its mode count) leave holes the next one fits
-    size_t p2 = size_t(1) << 26;
-    while ((p2 << 1) <= bytes) p2 <<= 1;
-    const size_t step = p2 >> 3;
-    return (bytes + step - 1) / step * step;
-  }
-  void* take(bool pinned, int dev, size_t bytes, size_t& granted) {
-    granted = size_class(bytes);
-    if (granted < kMedium) {  // small blocks are recycled by size class; a miss is carved out of a slab as well
-      std::lock_guard<std::mutex> lock(mu_);
-      auto& m = blocks_[key(pinned, dev)];
-      auto it = m.find(granted);
-      if (it != m.end()) {
-        void* p = it->second;
-        cached_[pinned] -= granted;
-        if (!pinned) in_use_[dev] += granted;
-        m.erase(it);
-        return p;
-      }
-    }
-    if (void* p = take_from_arenas(pinned, dev, granted)) return p;
-    // no arenas (fixed limit) or no room for another slab: a block of its own, recycled by size
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      auto& m = blocks_[key(pinned, dev)];
-      auto it = m.lower_bound(granted);
-      if (it != m.end() && it->first <= granted + granted / 2 + (size_t(1) << 20)) {  // close enough in size
-        void* p = it->second;
-        granted = it->first;
-        cached_[pinned] -= granted;
-        if (!pinned) in_use_[dev] += granted;
-        m.erase(it);
-        return p;
-      }
-    }
+// The process-wide cache of device blocks, pinned host blocks and streams (hostlogic/memory_cache.hpp: slab arenas, size
+// classes, footprint limits -- host-only bookkeeping, also compiled under the CPU sanitizers) over the HIP runtime.
+struct HipBackend {
+  using Stream = hipStream_t;
+  static void* alloc(bool pinned, size_t bytes) {
     void* p = nullptr;
-    hipError_t e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
-    if (e != hipSuccess) {  // make room and try once more
-      (void)hipGetLastError();  // clear HIP's sticky error: the launch wrappers return hipGetLastError()
-      trim();
-      e = pinned ? hipHostMalloc(&p, granted, hipHostMallocDefault) : hipMalloc(&p, granted);
-    }
-    hip_check(e, pinned ? "hipHostMalloc" : "hipMalloc");
-    if (!pinned) { std::lock_guard<std::mutex> lock(mu_); in_use_[dev] += granted; }
-    return p;
+    const hipError_t e = pinned ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+    if (e == hipSuccess) return p;
+    (void)hipGetLastError();  // clear HIP's sticky error: the launch wrappers return hipGetLastError()
+    return nullptr;
   }
-  void give(bool pinned, int dev, void* p, size_t granted) {
-    if (!p) return;
-    void* dead_arena = nullptr;
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      if (!pinned) {
-        size_t& used = in_use_[dev];
-        used = used >= granted ? used - granted : 0;
-      }
-      const bool fixed = limit_[pinned] != kAutoLimit;
-      Arena* home = nullptr;
-      std::vector<Arena>* home_list = nullptr;
-      for (int band = 0; band < kBands && !home; ++band) {
-        auto& av = arenas_[arena_key(pinned, dev, band)];
-        for (auto& a : av)
-          if (a.contains(p)) { home = &a; home_list = &av; break; }
-      }
-      // Small blocks wait in the size-class lists, as do blocks that have no slab; the others go back into their slab.
-      const bool listed = granted < kMedium || !home;
-      if (listed) {
-        bool keep;
-        if (fixed) keep = cached_[pinned] + granted <= limit_[pinned];
-        else if (home) keep = true;
-        else if (pinned) keep = cached_[1] + granted <= (size_t(2) << 30);
-        // keep while the library's footprint on the device stays below three quarters of its memory
-        else keep = in_use_[dev] + cached_[0] + arena_bytes_locked(false, dev) + granted <= device_total_locked(dev) / 4 * 3;
-        if (keep) {
-          blocks_[key(pinned, dev)].emplace(granted, p);
-          cached_[pinned] += granted;
-          return;
-        }
-      }
-      if (home) {
-        home->put_back(p, granted);
-        p = nullptr;
-        // with a fixed limit (storm_memory_cache_limit) an empty slab goes back as soon as it exceeds the limit
-        if (fixed && home->free_bytes == home->size && cached_[pinned] + arena_free_locked(pinned) > limit_[pinned]) {
-          dead_arena = home->base;
-          home_list->erase(home_list->begin() + (home - home_list->data()));
-        }
-      }
-    }
-    if (dead_arena) { if (pinned) (void)hipHostFree(dead_arena); else (void)hipFree(dead_arena); }
-    if (!p) return;
-    if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+  static void release(bool pinned, void* p) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+  [[noreturn]] static void alloc_failed(bool pinned, size_t bytes) {
+    fail(STORM_ERR_HIP, std::string(pinned ? "hipHostMalloc" : "hipMalloc") + " of " + std::to_string(bytes) + " bytes failed");
   }
-  hipStream_t take_stream(int dev) {
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      auto& v = streams_[dev];
-      if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
-    }
+  static size_t device_total(int dev) {
+    size_t bytes = 0;
+    if (hipDeviceTotalMem(&bytes, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return bytes;
+  }
+  static int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+  static void set_device(int dev) { (void)hipSetDevice(dev); }
+  static Stream stream_create() {
     hipStream_t st = nullptr;
     hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
     return st;
   }
-  void give_stream(int dev, hipStream_t st) {  // st must be idle
-    if (!st) return;
-    std::lock_guard<std::mutex> lock(mu_);
-    auto& v = streams_[dev];
-    if (v.size() < 64) { v.push_back(st); return; }
-    (void)hipStreamDestroy(st);
-  }
-  // Returns every cached block and every arena nothing is carved from to the runtime (each device's with that device current).
-  void trim() { release_idle(true); }
-  void set_limit(bool pinned, size_t bytes) {
-    bool over;
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      limit_[pinned] = bytes;
-      over = cached_[pinned] + arena_free_locked(pinned) > bytes;
-    }
-    if (over) trim();  // (gives back idle blocks of both kinds; what is in use follows when it is released)
-  }
-  size_t cached(bool pinned) {
-    std::lock_guard<std::mutex> lock(mu_);
-    return cached_[pinned] + arena_free_locked(pinned);
-  }
-
- private:
-  static int key(bool pinned, int dev) { return dev * 2 + (pinned ? 1 : 0); }
-  // arenas_: keys 0 .. 2 = pinned host memory (band 0 .. 2); 3 + 3 * device + band = device memory
-  static constexpr int kBands = 3;  // below 1 MiB, [1, 64) MiB, 64 MiB and more: each band has slabs of its own
-  static int band_of(size_t granted) { return granted >= kLarge ? 2 : granted >= kMedium ? 1 : 0; }
-  static int arena_key(bool pinned, int dev, int band) { return pinned ? band : kBands + dev * kBands + band; }
-  static bool arena_key_pinned(int k) { return k < kBands; }
-  static int arena_key_dev(int k) { return k < kBands ? 0 : (k - kBands) / kBands; }
-  // idle slab memory: what a trim would hand back (slabs nothing is carved from; the holes of a slab in use stay)
-  size_t arena_free_locked(bool pinned) const {
-    size_t f = 0;
-    for (auto& kv : arenas_)
-      if (arena_key_pinned(kv.first) == pinned)
-        for (auto& a : kv.second) if (a.free_bytes == a.size) f += a.size;
-    return f;
-  }
-  size_t arena_bytes_locked(bool pinned, int dev) {
-    size_t f = 0;
-    for (int band = 0; band < kBands; ++band) for (auto& a : arenas_[arena_key(pinned, dev, band)]) f += a.size;
-    return f;
-  }
-  size_t device_total_locked(int dev) {
-    auto it = total_.find(dev);
-    if (it == total_.end()) {
-      size_t bytes = 0;
-      if (hipDeviceTotalMem(&bytes, dev) != hipSuccess) { (void)hipGetLastError(); bytes = size_t(64) << 30; }
-      it = total_.emplace(dev, bytes).first;
-    }
-    return it->second;
-  }
-  // A block out of the arenas (device memory of `dev`, the current device, or pinned host memory), growing them if need
-  // be; nullptr: the caller falls back to a block of its own (arenas are off under a fixed limit, or there is no room for
-  // another slab).  Three bands with slabs of their own, so that the many small and medium blocks of short-lived handles
-  // do not fragment the slabs the multi-GB staging blocks need.
-  void* take_from_arenas(bool pinned, int dev, size_t granted) {
-    const int band = band_of(granted);
-    const int ak = arena_key(pinned, dev, band);
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      if (limit_[pinned] != kAutoLimit) return nullptr;
-      for (auto& a : arenas_[ak])
-        if (void* p = a.carve(granted)) { if (!pinned) in_use_[dev] += granted; return p; }
-    }
-    std::lock_guard<std::mutex> grow(grow_mu_);  // one slab at a time; whoever waited here looks again first
-    size_t want = 0;
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      for (auto& a : arenas_[ak])
-        if (void* p = a.carve(granted)) { if (!pinned) in_use_[dev] += granted; return p; }
-      // Slab sizes.  Fresh memory is not free: when the driver has to clear it first (memory another process released
-      // shortly before) hipMalloc / hipHostMalloc take ~30 ms per GB -- a 144 GB slab was measured at 4.1-4.4 s, at
-      // 0.5 ms when the memory was clean -- and every stream of the process stalls meanwhile.  So slabs follow the need:
-      // the first one is small, later ones double up to a ceiling, and the request itself sets the minimum (twice its
-      // size for the large band).  Device: 4 GiB up to 32 GiB (blocks of 64 MiB and more), 256 MiB up to 2 GiB (medium),
-      // 16 MiB up to 256 MiB (small); never past 3/4 of the device in all.  Pinned host: 1 GiB up to 8 GiB, 128 MiB up
-      // to 1 GiB, 8 MiB up to 128 MiB; 64 GiB in all.
-      const size_t total = pinned ? size_t(64) << 30 : device_total_locked(dev);
-      const size_t have = arena_bytes_locked(pinned, dev);
-      const auto& av = arenas_[ak];
-      const size_t kFirst[2][kBands] = {{size_t(16) << 20, size_t(256) << 20, size_t(4) << 30}, {size_t(8) << 20, size_t(128) << 20, size_t(1) << 30}};
-      const size_t kTop[2][kBands] = {{size_t(256) << 20, size_t(2) << 30, size_t(32) << 30}, {size_t(128) << 20, size_t(1) << 30, size_t(8) << 30}};
-      const size_t first = kFirst[pinned][band], top = kTop[pinned][band];
-      want = av.empty() ? first : std::min(av.back().size * 2, top);
-      want = std::max(want, band == 2 ? granted * 2 : granted + granted / 4);
-      want = (want + (size_t(2) << 20) - 1) >> 21 << 21;
-      const size_t cap = pinned ? total : total / 4 * 3;
-      if (have + cached_[pinned] + want > cap) want = granted;
-      if (have + want > cap) return nullptr;
-    }
-    void* base = nullptr;
-    while ((pinned ? hipHostMalloc(&base, want, hipHostMallocDefault) : hipMalloc(&base, want)) != hipSuccess) {
-      (void)hipGetLastError();
-      base = nullptr;
-      if (want <= granted) return nullptr;
-      want = std::max(granted, want / 2);
-    }
-    std::lock_guard<std::mutex> lock(mu_);
-    Arena a;
-    a.base = static_cast<char*>(base); a.size = want; a.free_bytes = want;
-    a.holes.emplace(0, want);
-    void* p = a.carve(granted);
-    arenas_[ak].push_back(std::move(a));
-    if (!pinned) in_use_[dev] += granted;
-    return p;
-  }
-  // All cached blocks and all empty arenas go back to the runtime.
-  void release_idle(bool everything) {
-    std::map<int, std::multimap<size_t, void*>> blocks;
-    std::map<int, std::vector<void*>> slabs;
-    {
-      std::lock_guard<std::mutex> lock(mu_);
-      if (everything) {
-        blocks.swap(blocks_);
-        cached_[0] = cached_[1] = 0;
-        // listed blocks that were carved out of a slab go back into it
-        for (auto& kv : blocks) {
-          const bool pinned = kv.first & 1;
-          const int dev = kv.first >> 1;
-          for (auto it = kv.second.begin(); it != kv.second.end();) {
-            Arena* home = nullptr;
-            for (int band = 0; band < kBands && !home; ++band)
-              for (auto& a : arenas_[arena_key(pinned, dev, band)])
-                if (a.contains(it->second)) { home = &a; break; }
-            if (home) { home->put_back(it->second, it->first); it = kv.second.erase(it); }
-            else ++it;
-          }
-        }
-      }
-      for (auto& kv : arenas_) {
-        const bool pinned = arena_key_pinned(kv.first);
-        auto& av = kv.second;
-        for (size_t k = 0; k < av.size();) {
-          const bool idle = av[k].free_bytes == av[k].size;
-          const bool over = limit_[pinned] != kAutoLimit && cached_[pinned] + arena_free_locked(pinned) > limit_[pinned];
-          if (idle && (everything || over)) { slabs[kv.first].push_back(av[k].base); av.erase(av.begin() + k); }
-          else ++k;
-        }
-      }
-    }
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    for (auto& kv : blocks) {
-      const bool pinned = kv.first & 1;
-      if (!pinned) (void)hipSetDevice(kv.first >> 1);
-      for (auto& b : kv.second) { if (pinned) (void)hipHostFree(b.second); else (void)hipFree(b.second); }
-    }
-    for (auto& kv : slabs) {
-      const bool pinned = arena_key_pinned(kv.first);
-      if (!pinned) (void)hipSetDevice(arena_key_dev(kv.first));
-      for (void* p : kv.second) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
-    }
-    (void)hipSetDevice(prev);
-  }
-  std::mutex mu_, grow_mu_;
-  std::map<int, std::multimap<size_t, void*>> blocks_;
-  std::map<int, std::vector<hipStream_t>> streams_;
-  std::map<int, std::vector<Arena>> arenas_;       // by arena_key(pinned, device, band)
-  static constexpr size_t kAutoLimit = ~size_t(0);
-  size_t cached_[2] = {0, 0};                      // small blocks kept for reuse: device (all devices together), pinned host
-  std::map<int, size_t> in_use_, total_;           // per device: bytes handed out, memory of the device
-  size_t limit_[2] = {kAutoLimit, kAutoLimit};     // footprint rules above until storm_memory_cache_limit sets figures
+  static void stream_destroy(Stream st) { (void)hipStreamDestroy(st); }
 };
+using MemoryCache = BasicMemoryCache<HipBackend>;
 
 // Growable device buffer (blocks come from / go back to the MemoryCache).
 template <class T>
@@ -864,87 +577,13 @@ void det_host(storm_solver* s, const double* freq, size_t n, double* det_out) {
   check_flags(s);  // synchronises
 }
 
-// ---- bracketing (reference src/bracket.rs), lock-step over all brackets ----
-struct Pt { double x, f; };
-
-inline double sign_of(double f) {  // f64::signum: by sign bit, NaN stays NaN
-  if (f != f) return f;
-  return std::signbit(f) ? -1.0 : 1.0;
-}
-inline uint64_t bits_of(double x) { uint64_t b; std::memcpy(&b, &x, 8); return b; }
-inline double from_bits(uint64_t b) { double x; std::memcpy(&x, &b, 8); return x; }
-
-inline double secant(Pt a, Pt b) {  // evaluate_secant(., ., 0), src/bracket.rs:73-75
-  const double y = 0.0;
-  return (y - b.f) / (a.f - b.f) * a.x + (y - a.f) / (b.f - a.f) * b.x;
-}
-inline double inverse_quadratic(Pt a, Pt b, Pt c) {  // src/bracket.rs:77-81
-  const double y = 0.0;
-  return (y - b.f) * (y - c.f) / (a.f - b.f) / (a.f - c.f) * a.x +
-         (y - a.f) * (y - c.f) / (b.f - a.f) / (b.f - c.f) * b.x +
-         (y - a.f) * (y - b.f) / (c.f - b.f) / (c.f - a.f) * c.x;
-}
-// ensure_maximal_bracket, src/bracket.rs:96-132; true = converged (x is the root as proposed).
-inline bool clamp_proposal(double upper, double lower, double& x, uint64_t ulp) {
-  if (!(upper > lower) || !std::isfinite(upper) || !std::isfinite(lower) || !(upper >= 0.0) || !(lower >= 0.0))
-    fail(STORM_ERR_BRACKET, "bracket must satisfy 0 <= lower < upper < inf");
-  const uint64_t ub = bits_of(upper), lb = bits_of(lower);
-  if (ub - lb <= ulp) return true;
-  uint64_t xb = bits_of(x);
-  if ((ub - lb) <= 2 * ulp) xb = lb + (ub - lb) / 2;
-  else if ((ub < xb) || (ub - xb) < ulp) xb = ub - ulp;
-  else if ((lb > xb) || (xb - lb) < ulp) xb = lb + ulp;
-  x = from_bits(xb);
-  return false;
-}
-
-struct BracketState {
-  Pt lower, upper, previous;
-  bool has_prev = false, done = false;
-  double root = 0.0, pending = 0.0;
-  uint64_t evals = 0;
-};
-
+// ---- bracketing (reference src/bracket.rs), lock-step over all brackets: hostlogic/brackets.hpp ----
 void refine_all(storm_solver* s, std::vector<BracketState>& br, uint64_t ulp) {
-  if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
-  if (!(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
-  std::vector<double> xs, fs;
-  std::vector<size_t> who;
-  for (;;) {
-    xs.clear(); who.clear();
-    for (size_t k = 0; k < br.size(); ++k) {
-      BracketState& b = br[k];
-      if (b.done) continue;
-      double x;
-      if (!b.has_prev) {
-        x = secant(b.lower, b.upper);
-      } else {
-        x = inverse_quadratic(b.lower, b.upper, b.previous);
-        if (x <= b.lower.x || x >= b.upper.x) x = secant(b.lower, b.upper);
-      }
-      if (clamp_proposal(b.upper.x, b.lower.x, x, ulp)) {
-        b.done = true; b.root = x;
-        continue;
-      }
-      b.pending = x;
-      xs.push_back(x); who.push_back(k);
-    }
-    if (xs.empty()) break;
-    fs.resize(xs.size());
-    det_host(s, xs.data(), xs.size(), fs.data());
-    s->stats.refine_evals += xs.size();
+  refine_brackets(br, ulp, [&](const double* xs, size_t n, double* fs) {
+    det_host(s, xs, n, fs);
+    s->stats.refine_evals += n;
     s->stats.refine_rounds += 1;
-    for (size_t q = 0; q < who.size(); ++q) {
-      BracketState& b = br[who[q]];
-      const Pt next{xs[q], fs[q]};
-      if (!std::isfinite(next.x) || !std::isfinite(next.f))
-        fail(STORM_ERR_NON_FINITE, "non-finite discriminant during bracket refinement");
-      b.evals += 1;
-      if (sign_of(b.upper.f) == sign_of(next.f)) { b.previous = b.upper; b.upper = next; }
-      else { b.previous = b.lower; b.lower = next; }
-      b.has_prev = true;
-    }
-  }
+  });
 }
 
 // ---- the same on the device (common_kernels.hip, "Bracketing on the device") ----
@@ -1525,25 +1164,7 @@ int storm_det_batch_device_noalloc(storm_solver* s, const double* d_freq, size_t
   });
 }
 
-// FilterSignSwap + finite filter (src/bracket.rs:236-250, src/dynamic_interface.rs:128-138) over the n scan values.
-static void filter_sign_swaps(const double* freq, const double* dets, size_t n, std::vector<BracketState>& br,
-                              std::vector<uint64_t>& idx, bool& invalid) {
-  invalid = false;
-  for (size_t i = 0; i + 1 < n; ++i) {
-    const double a = dets[i], b = dets[i + 1];
-    if (sign_of(a) != sign_of(b)) {
-      if (std::isfinite(a) && std::isfinite(b)) {
-        BracketState st;
-        st.lower = Pt{freq[i], a};
-        st.upper = Pt{freq[i + 1], b};
-        br.push_back(st);
-        idx.push_back(i);
-      } else {
-        invalid = true;
-      }
-    }
-  }
-}
+// (filter_sign_swaps: hostlogic/brackets.hpp)
 
 // scan_and_optimize with the filter, the compaction and the refinement on the device: the grid goes up once, the
 // brackets come down once (plus the scan values if the caller wants them).
@@ -2052,38 +1673,27 @@ struct storm_multi {
 };
 
 namespace {
-// Runs job(k) for k < n on n host threads (the caller's thread takes k = 0); the first failure wins and its message
-// becomes the caller's storm_last_error().
-template <class Job>
-void on_every_device(size_t n, Job&& job) {
-  std::vector<int> rc(n, STORM_OK);
-  std::vector<std::string> msg(n);
-  auto run = [&](size_t k) {
-    try {
-      rc[k] = job(k);
-      if (rc[k] != STORM_OK) msg[k] = g_error;  // (thread-local: read on the thread that failed)
-    } catch (const std::bad_alloc&) {  // (sizing a part: an exception must not leave a worker thread)
-      rc[k] = STORM_ERR_HIP;
-      msg[k] = "out of host memory";
-    } catch (const std::exception& e) {
-      rc[k] = STORM_ERR_INVALID_ARGUMENT;
-      msg[k] = e.what();
-    }
-  };
-  std::vector<std::thread> pool;
-  for (size_t k = 1; k < n; ++k) pool.emplace_back(run, k);
-  run(0);
-  for (auto& th : pool) th.join();
-  for (size_t k = 0; k < n; ++k)
-    if (rc[k] != STORM_OK) fail(rc[k], "device " + std::to_string(k) + ": " + msg[k]);
-}
+// The single-device C ABI as the device side of hostlogic/multi.hpp (orchestration, gather, deal).
+struct SolverOps {
+  using Solver = storm_solver*;
+  static int scan_brackets(Solver s, const double* freq, size_t n, storm_bracket* out, size_t cap, size_t* n_out, int* invalid,
+                           double* det_out, uint64_t* index_out) {
+    return storm_scan_brackets(s, freq, n, out, cap, n_out, invalid, det_out, index_out);
+  }
+  static int optimize_brackets(Solver s, storm_bracket* br, size_t n, uint64_t ulp) { return storm_optimize_brackets(s, br, n, ulp); }
+  static int eigenvector_batch(Solver s, const double* freq, size_t n, double* det_out, double* vec_out) {
+    return storm_eigenvector_batch(s, freq, n, det_out, vec_out);
+  }
+  static size_t n_int(Solver s) { return s->sys.n_int; }
+  static std::string last_error() { return g_error; }
+};
 }  // namespace
 
 extern "C" {
 
 void storm_shard_bounds(size_t n, size_t n_parts, size_t k, size_t* lo, size_t* hi) {
-  const size_t per = n_parts ? (n + n_parts - 1) / n_parts : n;
-  const size_t a = std::min(n, k * per), b = std::min(n, a + per);
+  size_t a, b;
+  shard_bounds(n, n_parts, k, a, b);
   if (lo) *lo = a;
   if (hi) *hi = b;
 }
@@ -2107,7 +1717,7 @@ int storm_multi_create(const storm_system_desc* desc, const int* devices, size_t
       const int r = storm_solver_create(desc, &q->solvers[k]);
       (void)hipSetDevice(prev);
       return r;
-    });
+    }, SolverOps::last_error);
     *out = q;
   });
   if (rc != STORM_OK && q) { storm_multi_destroy(q); if (out) *out = nullptr; }
@@ -2155,71 +1765,16 @@ int storm_multi_scan_and_optimize(storm_multi* q, const double* freq, size_t n, 
   if (had_invalid) *had_invalid = 0;
   return guarded([&] {
     if (!q || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
-    if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
     std::lock_guard<std::mutex> lock(q->mu);
-    const size_t D = q->solvers.size();
-    // 1. every device scans its slice (+1 halo point) and filters its own adjacent pairs
-    struct Part { size_t lo = 0; std::vector<storm_bracket> br; std::vector<uint64_t> idx; std::vector<double> det; int invalid = 0; };
-    std::vector<Part> parts(D);
-    on_every_device(D, [&](size_t k) {
-      Part& p = parts[k];
-      size_t lo, hi;
-      storm_shard_bounds(n, D, k, &lo, &hi);
-      p.lo = lo;
-      const size_t m = std::min(hi + 1, n) - lo;  // with the halo
-      if (hi == lo) return int(STORM_OK);
-      p.br.resize(m); p.idx.resize(m);
-      if (det_out) p.det.resize(m);
-      size_t found = 0;
-      const int rc = storm_scan_brackets(q->solvers[k], freq + lo, m, p.br.data(), m, &found, &p.invalid,
-                                         det_out ? p.det.data() : nullptr, p.idx.data());
-      p.br.resize(found); p.idx.resize(found);
-      if (rc == STORM_OK && det_out) std::memcpy(det_out + lo, p.det.data(), (hi - lo) * sizeof(double));  // owned points only
-      return rc;
-    });
-    // 2. the gather: slices are contiguous, so rank order is ascending bracket order
-    std::vector<storm_bracket> all;
-    std::vector<uint64_t> idx;
-    int invalid = 0;
-    for (const Part& p : parts) {
-      invalid |= p.invalid;
-      for (size_t j = 0; j < p.br.size(); ++j) { all.push_back(p.br[j]); idx.push_back(p.idx[j] + p.lo); }
-    }
-    if (had_invalid) *had_invalid = invalid;
-    *n_out = all.size();
-    if (all.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
-    // 3. the deal: bracket j goes to device j mod D
-    std::vector<std::vector<storm_bracket>> share(D);
-    for (size_t j = 0; j < all.size(); ++j) share[j % D].push_back(all[j]);
-    on_every_device(D, [&](size_t k) {
-      return share[k].empty() ? int(STORM_OK) : storm_optimize_brackets(q->solvers[k], share[k].data(), share[k].size(), ulp);
-    });
-    for (size_t j = 0; j < all.size(); ++j) {
-      out[j] = share[j % D][j / D];
-      if (index_out) index_out[j] = idx[j];
-    }
+    multi_scan_and_optimize<SolverOps>(q->solvers, freq, n, ulp, out, cap, n_out, had_invalid, det_out, index_out);
   });
 }
 
 int storm_multi_eigenvector_batch(storm_multi* q, const double* freq, size_t n, double* det_out, double* vec_out) {
   return guarded([&] {
     if (!q || (n && (!freq || !vec_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
-    if (n == 0) return;
     std::lock_guard<std::mutex> lock(q->mu);
-    const size_t D = q->solvers.size(), len = (q->solvers[0]->sys.n_int + 1) * 4;
-    on_every_device(D, [&](size_t k) {
-      std::vector<double> f, d, v;
-      for (size_t j = k; j < n; j += D) f.push_back(freq[j]);
-      if (f.empty()) return int(STORM_OK);
-      d.resize(f.size()); v.resize(f.size() * len);
-      const int rc = storm_eigenvector_batch(q->solvers[k], f.data(), f.size(), d.data(), v.data());
-      if (rc != STORM_OK) return rc;
-      for (size_t i = 0, j = k; j < n; j += D, ++i) {
-        std::memcpy(vec_out + j * len, v.data() + i * len, len * sizeof(double));
-        if (det_out) det_out[j] = d[i];
-      }
-      return int(STORM_OK);
-    });
+    multi_eigenvector_batch<SolverOps>(q->solvers, freq, n, det_out, vec_out);
   });
 }
 
