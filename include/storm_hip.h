@@ -399,9 +399,9 @@ int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value
  * sweep).  "segments": 0 (default) = in the FMA build every eigenvector pass and every discriminant batch of at most
  * 3072 frequencies per class (the refinement rounds) goes through segment transfer matrices, with the tolerances of
  * "arithmetic" = 1 (a pass in which a transfer matrix outgrows the guard is redone sequentially and counted in
- * segment_fallbacks); -1 = never.  The parity build never takes that path.  "device_brackets": 0 (default for a sweep) =
- * InverseQuadratic::optimize (src/bracket.rs:148-223) as a host loop over the brackets still open, 1 = as device kernels
- * over all brackets every round; same brackets, roots, evals and counters either way. */
+ * segment_fallbacks); -1 = never.  The parity build never takes that path.  A sweep runs
+ * InverseQuadratic::optimize (src/bracket.rs:148-223) as a host loop over the brackets still open (one batched device
+ * evaluation per round); "coupling_matrix" / "coupling_matrix_tile" as for a post-processing handle. */
 int storm_sweep_stats(storm_sweep* sweep, storm_stats* out, int reset);
 int storm_sweep_set_option(storm_sweep* sweep, const char* key, int64_t value);
 

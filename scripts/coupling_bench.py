@@ -29,9 +29,13 @@ x = grid
 metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x ** 2,
           "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}
 raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
-for tile, arith, M in [(t, a, m) for t in (8, 16) for a in (0, 1) for m in sizes]:
+# parity build: vector walk with 8 x 8 and 16 x 16 tiles; FMA build: the same two, then the matrix-pipe walk (tile = 0 here)
+# (tile = -16 / -32 here: the matrix-pipe walk with that tile)
+for tile, arith, M in [(t, a, m) for a in (0, 1) for t in ((8, 16) if a == 0 else (16, -16, -32)) for m in sizes]:
     raw.set_option("arithmetic", arith)
-    raw.set_option("coupling_tile", tile)
+    raw.set_option("coupling_matrix", 1 if tile < 0 else 0)
+    raw.set_option("coupling_matrix_tile", -tile if tile < 0 else 0)
+    raw.set_option("coupling_tile", max(tile, 0))
     sel = np.arange(M) % freqs.size
     f, e, fl = freqs[sel], ells[sel], np.ascontiguousarray(fields[sel])
     raw.coupling_matrices(e, f, fl, 0, metric)

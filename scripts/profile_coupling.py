@@ -1,5 +1,6 @@
 """Runs storm_coupling_matrices a few times on M modes (default 512) for rocprofv3 passes.
-usage: profile_coupling.py [M] [reps] [arithmetic] [sorted: 1 = modes grouped by degree, as scans deliver them]"""
+usage: profile_coupling.py [M] [reps] [arithmetic] [sorted: 1 = modes grouped by degree, as scans deliver them] [tile of the
+matrix-pipe walk: 0 (automatic), 16, 32]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +30,8 @@ metric = {"alpha": 1e-3 * x ** 2, "dalpha": 2e-3 * x ** 2, "ddalpha": 4e-3 * x *
           "beta": -1.2e-3 * x ** 2, "dbeta": -2.4e-3 * x ** 2, "ddbeta": -4.8e-3 * x ** 2}
 raw = ffi.HipPostproc({k: on_grid.field(k) for k in ffi.MODEL_FIELDS})
 raw.set_option("arithmetic", arith)
+if len(sys.argv) > 5:
+    raw.set_option("coupling_matrix_tile", int(sys.argv[5]))
 f, e, fl = freqs[sel], ells[sel], np.ascontiguousarray(fields[sel])
 for _ in range(reps):
     out = raw.coupling_matrices(e, f, fl, 0, metric)

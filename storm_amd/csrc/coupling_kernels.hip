@@ -82,42 +82,51 @@ PDEV void coupling_stage(const CouplingArgs& a, size_t lrow, size_t rrow, size_t
 typedef const double __attribute__((address_space(4))) * cp_const_ptr;
 
 #ifdef STORM_FAST_BUILD
-// Which 16 x 16 tiles the matrix-pipe walk takes (FMA build): full tiles whose 16 left modes share one degree and whose 16
-// right modes share one; of those with all ten factors zero (degrees more than 2 apart) only the ones whose 32 modes are
-// tame (see coupling_body) -- `null_walk` -- the others stay with the vector walk's full expression.  Wave-uniform, and
-// the same for every wave of a workgroup and for both kernels (every wave looks at the same 32 modes).
-struct CpMatrixTile { bool take, null_walk; };
-PDEV CpMatrixTile cp_matrix_tile(const CouplingArgs& a, size_t l0, size_t r0, int lane) {
-  const size_t M = a.n_modes;
-  if (!(l0 + 16 <= M && r0 + 16 <= M)) return CpMatrixTile{false, false};
-  const int mi = lane & 15;
-  const size_t lmi = l0 + mi, rmi = r0 + mi;
-  if (!__all(a.ell_index[lmi] == a.ell_index[l0] && a.ell_index[rmi] == a.ell_index[r0])) return CpMatrixTile{false, false};
-  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[l0] * a.n_ell + a.ell_index[r0]) * kCouplingConsts;
-  bool all_zero = true;
-#pragma unroll
-  for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && q[k] == 0.0;
-  if (!all_zero) return CpMatrixTile{true, false};
-  const bool tame = a.tame != nullptr && a.weights_tame && __all(a.tame[lmi] != 0 && a.tame[rmi] != 0);
-  return CpMatrixTile{tame, tame};
+// The matrix-pipe walk (FMA build) works on the ORDERED mode list of a problem (CouplingArgs::order, made by the host:
+// coupling_order in storm_hip.hip): the caller's modes grouped by degree, every group padded to a multiple of 16
+// positions, so that the 16 left modes of a tile share one degree and its 16 right modes share one -- the ten Gaunt
+// factors are then constants of the tile.  order[pos] = the caller's index of the mode at padded position pos, or -1 for
+// padding; the first position of a tile is never padding.  A padding position computes with its tile's first mode and
+// stores nothing.  (Round 2 left the tiles that straddle two degrees to the vector walk, side by side with this one: 3 % of
+// the tiles of M = 1024 modes of two degrees took 9.5 ms there, one wave per SIMD walking the grid point by point at ~3000
+// cycles per point, next to 7.9 ms for the other 97 % here.)
+PDEV size_t cp_mode_at(const CouplingArgs& a, size_t pos, size_t tile_first) {
+  const int k = a.order[pos];
+  return size_t(k >= 0 ? k : a.order[tile_first]);
 }
 
 constexpr int kCpRing = 3;  // chunks staged at once in the matrix-pipe walk (kCpRing - 1 requested ahead).  Measured, M = 1024 of one
 // degree | 80 modes of three degrees repeated to M = 512 (few eligible tiles: latency counts): ring of 2: 8.2 | 7.7 ms, 3: 8.7 | 5.2 ms,
 // 4: 10.8 | 5.3 ms (42 KB of LDS: three workgroups per CU instead of five).
 
+// LDS image of a staged plane in the matrix-pipe walks: [mode][point] in groups of four modes (one LDS-DMA instruction: 4
+// modes x 8 points x 8 B) that start kCpGroup = 34 doubles apart, not 32: lane (mode, point) reads mode * 64 B + point * 8 B,
+// and with groups 256 B apart the four groups of a side land on the same banks (a 4-way conflict on every operand read:
+// SQ_LDS_BANK_CONFLICT 8.8e8 cycles per launch at M = 1024, profiles/r03_pmc_coupling_matrix.txt); two doubles of padding
+// turn the group index into a bank offset of 4, and the 32 lanes of a half-wave hit 32 distinct bank pairs.
+constexpr int kCpGroup = 4 * kCpChunk + 2;
+PDEV int cp_slot(int mode) { return (mode >> 2) * kCpGroup + (mode & 3) * kCpChunk; }
+
 PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
-  constexpr int TILE = 16, kCpTile = 16, kCpPlane = CpGeom<16>::kPlane, kCpBufs = kCpRing;
-  constexpr int kCpTileDoubles = CpGeom<16>::kFieldTile + kCpChunk * kCouplingWeights;  // fields, then the points' weights
+  constexpr int kCpTile = 16, kCpPlane = 4 * kCpGroup, kCpFields = 9 * kCpPlane, kCpBufs = kCpRing;
+  constexpr int kCpTileDoubles = kCpFields + kCpChunk * kCouplingWeights;  // fields, then the points' weights
   __shared__ __attribute__((aligned(16))) double tiles[kCpBufs][kCpTileDoubles];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const size_t M = a.n_modes, np = a.n_pts;
-  const size_t l0 = (size_t)tile_l * kCpTile, r0 = (size_t)tile_r * kCpTile;
-  const CpMatrixTile which = cp_matrix_tile(a, l0, r0, lane);
-  if (!which.take) return;
-  const bool null_walk = which.null_walk;
-  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[l0] * a.n_ell + a.ell_index[r0]) * kCouplingConsts;
+  const size_t l0 = (size_t)tile_l * kCpTile, r0 = (size_t)tile_r * kCpTile;  // positions in the ordered, padded list
+  const size_t lfirst = size_t(a.order[l0]), rfirst = size_t(a.order[r0]);
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lfirst] * a.n_ell + a.ell_index[rfirst]) * kCouplingConsts;
+  // Degrees more than 2 apart: all ten factors are zero and, if the 32 modes are tame (see coupling_body), what is left of
+  // l_zero is two instructions per four points on four of the nine planes.  Wave-uniform, the same for all four waves.
+  bool null_walk;
+  {
+    bool all_zero = true;
+#pragma unroll
+    for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && q[k] == 0.0;
+    const size_t lt = cp_mode_at(a, l0 + (lane & 15), l0), rt = cp_mode_at(a, r0 + (lane & 15), r0);
+    null_walk = all_zero && a.tame != nullptr && a.weights_tame && __all(a.tame[lt] != 0 && a.tame[rt] != 0);
+  }
   const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
   const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
   const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
@@ -156,7 +165,7 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
         size_t pt = rc0 + (size_t)(word / (2 * kCouplingWeights));
         pt = pt < np ? pt : np - 1;
         const char* src = reinterpret_cast<const char*>(a.weights + pt * kCouplingWeights) + (word % (2 * kCouplingWeights)) * 4;
-        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + CpGeom<TILE>::kFieldTile + h * 32), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + kCpFields + h * 32), 4, 0, 0);
       }
     };
     // A ring of kCpBufs staged chunks, kCpBufs - 1 of them requested ahead: a chunk of this walk is ~500 cycles of work
@@ -170,8 +179,9 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     // points x 16 modes per instruction, i.e. 16 cache lines touched for 256 bytes -- at this walk's pace the address
     // path of those requests was the bound: 14 ms at M = 1024 of one degree whatever the lookahead).  Wave w stages
     // modes 4w .. 4w+3 of every plane.
-    const size_t lrow_m = a.rows ? (size_t)a.rows[l0 + 4 * wave + (lane >> 4)] : l0 + 4 * wave + (lane >> 4);
-    const size_t rrow_m = a.rows ? (size_t)a.rows[r0 + 4 * wave + (lane >> 4)] : r0 + 4 * wave + (lane >> 4);
+    const size_t lstage = cp_mode_at(a, l0 + 4 * wave + (lane >> 4), l0), rstage = cp_mode_at(a, r0 + 4 * wave + (lane >> 4), r0);
+    const size_t lrow_m = a.rows ? (size_t)a.rows[lstage] : lstage;
+    const size_t rrow_m = a.rows ? (size_t)a.rows[rstage] : rstage;
     auto stage_fields = [&](size_t rc0, double* tile) {
       constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
       size_t pt = rc0 + (size_t)((lane & 15) >> 1);
@@ -181,7 +191,7 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
         if (null_walk && !(pl == 2 || pl == 3 || pl == 4 || pl == 8)) continue;
         const double* row = a.fields + ((pl < 4 ? lrow_m : rrow_m) * kPostFields + kPlanes[pl]) * np;
         const char* src = reinterpret_cast<const char*>(row + pt) + (lane & 1) * 4;
-        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + wave * 32), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCpPlane + wave * kCpGroup), 4, 0, 0);
       }
     };
     auto request = [&](size_t chunk) {
@@ -206,16 +216,17 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
       const double* __restrict__ t = tiles[chunk % kCpBufs];
       const int c = grp * 4 + kpt;
       const bool valid = rc0 + c < np;
-      const double* __restrict__ u = t + CpGeom<TILE>::kFieldTile + c * kCouplingWeights;
+      const double* __restrict__ u = t + kCpFields + c * kCouplingWeights;
+      const int at = cp_slot(mi) + c;
       // a point past the grid contributes nothing: every left operand is linear in the left fields
-      const double lxr = valid ? t[0 * kCpPlane + mi * kCpChunk + c] : 0.0, lxh = valid ? t[1 * kCpPlane + mi * kCpChunk + c] : 0.0;
-      const double lpsi = valid ? t[2 * kCpPlane + mi * kCpChunk + c] : 0.0, lp = valid ? t[3 * kCpPlane + mi * kCpChunk + c] : 0.0;
-      const double rxr = t[4 * kCpPlane + mi * kCpChunk + c], rxh = t[5 * kCpPlane + mi * kCpChunk + c];
+      const double lxr = valid ? t[0 * kCpPlane + at] : 0.0, lxh = valid ? t[1 * kCpPlane + at] : 0.0;
+      const double lpsi = valid ? t[2 * kCpPlane + at] : 0.0, lp = valid ? t[3 * kCpPlane + at] : 0.0;
+      const double rxr = t[4 * kCpPlane + at], rxh = t[5 * kCpPlane + at];
       const double eb = u[CW_EB], rho = u[CW_RHO], mrot = u[CW_MROT], c1 = u[CW_C1], tr2 = u[CW_TR2];
       if (null_walk) {
         // l_zero += trap r^2 (psi_l rho'_r tea - (rho psi_l + p_l) xi_r adtea / x): one right field per output half
         if (half == 0) {
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * u[CW_TEA]), t[8 * kCpPlane + mi * kCpChunk + c], acc[2], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * u[CW_TEA]), t[8 * kCpPlane + at], acc[2], 0, 0, 0);
         } else {
           const double a0r = -(tr2 * ((u[CW_RX] * u[CW_ADTEA]) * (rho * lpsi + lp)));
           acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0r, rxr, acc[2], 0, 0, 0);
@@ -238,8 +249,8 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
         acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxr * ipr), rxr, acc[4], 0, 0, 0);
         acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxh * iph), rxh, acc[4], 0, 0, 0);
       } else {
-        const double rtp = t[6 * kCpPlane + mi * kCpChunk + c], rtn = t[7 * kCpPlane + mi * kCpChunk + c];
-        const double rrho = t[8 * kCpPlane + mi * kCpChunk + c];
+        const double rtp = t[6 * kCpPlane + at], rtn = t[7 * kCpPlane + at];
+        const double rrho = t[8 * kCpPlane + at];
         const double vol2 = u[CW_VOL2], vrot = u[CW_VOL2ROT];
         const double c_s = ipr * u[CW_U4] + q2 * u[CW_U5], c_h2 = ipr * u[CW_U2] + k6x2 * eb;
         const double bs = mrot * (vol2 * c_s), bh2 = mrot * (vol2 * c_h2);
@@ -294,13 +305,14 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     __syncthreads();
     if (grp == 0) {
       const size_t mm2 = M * M;
-      const size_t rj = r0 + (size_t)(lane & 15);
-      const double F = a.freq[rj];
+      const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
+      const double F = a.freq[rj >= 0 ? rj : 0];
       bool ok = true;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const size_t li = l0 + (size_t)((lane >> 4) + 4 * v);
-        const size_t at = li + rj * M;
+        const int li = a.order[l0 + (size_t)((lane >> 4) + 4 * v)];
+        if (rj < 0 || li < 0) continue;
+        const size_t at = size_t(li) + size_t(rj) * M;
         if (null_walk) {
           if (half == 0) {
             const double lz = lz0[v * 64 + lane] + acc[2][v];
@@ -324,6 +336,203 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     }
     return;
   }
+}
+// ---- The same walk on 32 x 32 tiles (round 3) ----
+// A workgroup stages the fields of 32 left and 32 right positions once per chunk and each of its four waves owns one
+// 16 x 16 sub-tile with ALL eight accumulators and all 21 instructions per four points (both groups of a chunk): half the
+// bytes per (pair, point) of the 16 x 16 walk (its bound when the modes are all distinct: 5 B per pair and point for 0.66
+// SIMD-cycles of matrix pipe), no cross-wave reduction at the end, and the addresses of the staging requests are a
+// per-lane constant plus a wave-uniform chunk offset (the 16 x 16 walk recomputes and clamps them per chunk: ~6 of its ~9
+// vector instructions per matrix instruction).  The two 16-blocks of a side may belong to different degrees (groups are
+// padded to 16 positions, not 32): every wave has its own Gaunt factors and its own choice of the two-instruction form.
+// A side's last block may be all padding (odd number of blocks): its waves stage their share and compute nothing.
+constexpr int kCp32Plane = 8 * kCpGroup;                               // doubles per plane: [mode of the side][point], padded groups
+constexpr int kCp32Fields = 9 * kCp32Plane;                            // 4 left + 5 right planes
+constexpr int kCp32TileDoubles = kCp32Fields + kCpChunk * kCouplingWeights + 32;   // + the points' weights (+ pad to 256 B)
+constexpr int kCp32Ring = 3;   // (a ring of 2 with four workgroups per CU was measured: 8.7 vs 8.2 ms at M = 1024 -- the compiler
+// does not reach four waves per SIMD at 116 registers, and with two a chunk of lookahead is not enough)
+
+PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) double tiles[kCp32Ring][kCp32TileDoubles];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int bl = wave >> 1, br = wave & 1;
+  const size_t M = a.n_modes, np = a.n_pts, n_pad = a.n_pad;
+  const size_t side_l = (size_t)tile_l * 32, side_r = (size_t)tile_r * 32;   // positions in the ordered, padded list
+  const size_t l0 = side_l + 16 * bl, r0 = side_r + 16 * br;
+  // a block past the list's end (odd number of 16-blocks) does not exist; the first position of an existing block is a mode
+  const bool exists = l0 < n_pad && r0 < n_pad;
+  const size_t lfirst = size_t(a.order[exists ? l0 : side_l]), rfirst = size_t(a.order[exists ? r0 : side_r]);
+  const double* __restrict__ q = a.consts + ((size_t)a.ell_index[lfirst] * a.n_ell + a.ell_index[rfirst]) * kCouplingConsts;
+  const double q2 = q[CQ_Q2], q2_hrd = q[CQ_Q2_HRD], q2_hld = q[CQ_Q2_HLD], q2_h = q[CQ_Q2_H];
+  const double q_rt_p = q[CQ_RT_P], q_rt_n = q[CQ_RT_N], q_ht_p = q[CQ_HT_P], q_ht_n = q[CQ_HT_N];
+  const double ipr = q[CQ_IPR], iph = q[CQ_IPH];
+  const double k6 = ipr + 6.0 * q2;
+  const double q2x2 = 2.0 * q2, q2hx2 = 2.0 * q2_h, k6x2 = 2.0 * k6;
+  bool null_walk = false;
+  if (exists) {
+    bool all_zero = true;
+#pragma unroll
+    for (int k = 0; k < kCouplingConsts; ++k) all_zero = all_zero && q[k] == 0.0;
+    const size_t lt = cp_mode_at(a, l0 + (lane & 15), l0), rt = cp_mode_at(a, r0 + (lane & 15), r0);
+    null_walk = all_zero && a.tame != nullptr && a.weights_tame && __all(a.tame[lt] != 0 && a.tame[rt] != 0);
+  }
+  // the workgroup stages the four planes of the two-instruction form only if none of its waves needs more
+  const bool null_stage = __syncthreads_and(null_walk || !exists) != 0;
+  // ---- staging: wave w requests slots 8w .. 8w + 7 of each side, two instructions per plane (4 slots x 8 points x 8 B
+  // each: 16 consecutive lanes on the 64 consecutive bytes of one mode's chunk).  Per-lane constants: the byte address
+  // of point 0 of the lane's two left and two right modes' field blocks plus its 4 bytes of the 64; per chunk a
+  // wave-uniform offset.
+  const char* lbase[2];
+  const char* rbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const size_t slot = size_t(8 * wave + 4 * j + (lane >> 4));
+    size_t lp = side_l + slot, rp = side_r + slot;
+    // (a slot past the list's end or a padding position stages its side's first mode: never read into a stored result)
+    const int lk = lp < n_pad ? a.order[lp] : -1, rk = rp < n_pad ? a.order[rp] : -1;
+    const size_t lmode = size_t(lk >= 0 ? lk : a.order[side_l]), rmode = size_t(rk >= 0 ? rk : a.order[side_r]);
+    const size_t lrow = a.rows ? (size_t)a.rows[lmode] : lmode, rrow = a.rows ? (size_t)a.rows[rmode] : rmode;
+    lbase[j] = reinterpret_cast<const char*>(a.fields + lrow * kPostFields * np) + (lane & 15) * 4;
+    rbase[j] = reinterpret_cast<const char*>(a.fields + rrow * kPostFields * np) + (lane & 15) * 4;
+  }
+  const char* wbase = reinterpret_cast<const char*>(a.weights) + lane * 4;
+  const size_t n_chunks = (np - 1 + kCpChunk - 1) / kCpChunk;
+  constexpr int kAhead = kCp32Ring - 1;
+  auto request = [&](size_t chunk) {
+    // past the grid's end the last chunk is requested again (its data is never used): the count of requests in flight
+    // stays the same constant at every wait.  The last chunk itself may reach up to 7 points past the grid: those bytes
+    // belong to the next plane of the same mode (none of the staged planes is a mode's last) or to the 16 spare rows of
+    // the weights, and `valid` keeps them out of the sums.
+    const size_t ch = chunk < n_chunks ? chunk : n_chunks - 1;
+    const size_t byte0 = (1 + ch * kCpChunk) * sizeof(double);   // wave-uniform
+    double* tile = tiles[chunk % kCp32Ring];
+    constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
+#pragma unroll
+    for (int pl = 0; pl < 9; ++pl) {
+      if (null_stage && !(pl == 2 || pl == 3 || pl == 4 || pl == 8)) continue;
+      const size_t off = (size_t)kPlanes[pl] * np * sizeof(double) + byte0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* src = (pl < 4 ? lbase[j] : rbase[j]) + off;
+        __builtin_amdgcn_global_load_lds((cp_glb_ptr)src, (cp_lds_ptr)(tile + pl * kCp32Plane + (2 * wave + j) * kCpGroup), 4, 0, 0);
+      }
+    }
+    // the chunk's weights: 8 points x 160 B = five instructions of 256 B, waves 0..3 and wave 0 again
+    const char* wsrc = wbase + (1 + ch * kCpChunk) * (kCouplingWeights * sizeof(double));
+#pragma unroll
+    for (int h = 0; h < 5; ++h) {
+      if ((h & 3) != wave) continue;  // wave-uniform
+      __builtin_amdgcn_global_load_lds((cp_glb_ptr)(wsrc + h * 256), (cp_lds_ptr)(tile + kCp32Fields + h * 32), 4, 0, 0);
+    }
+  };
+  v4d acc[8];  // d_squared, d_linear, d_zero, lz1, lz2, r_linear, r_zero, lz0
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int mi = lane & 15, kpt = lane >> 4;
+  for (int k = 0; k < kAhead; ++k) request(k);
+  for (size_t chunk = 0; chunk < n_chunks; ++chunk) {
+    const size_t rc0 = 1 + chunk * kCpChunk;
+    if (null_stage) {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 10) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 9) : "memory");
+    } else {
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 20) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 19) : "memory");
+    }
+    __syncthreads();  // the chunk's data is in LDS for every wave, and every wave is done with the buffer of chunk - 1
+    request(chunk + kAhead);
+    if (!exists) continue;
+    const double* __restrict__ t = tiles[chunk % kCp32Ring];
+    const double* __restrict__ tl = t + cp_slot(16 * bl + mi);                  // this lane's left mode, plane 0
+    const double* __restrict__ tr = t + 4 * kCp32Plane + cp_slot(16 * br + mi);  // this lane's right mode, plane 4
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c = g * 4 + kpt;
+      const bool valid = rc0 + c < np;
+      const double* __restrict__ u = t + kCp32Fields + c * kCouplingWeights;
+      // a point past the grid contributes nothing: every left operand is linear in the left fields
+      const double lxr = valid ? tl[0 * kCp32Plane + c] : 0.0, lxh = valid ? tl[1 * kCp32Plane + c] : 0.0;
+      const double lpsi = valid ? tl[2 * kCp32Plane + c] : 0.0, lp = valid ? tl[3 * kCp32Plane + c] : 0.0;
+      const double rxr = tr[0 * kCp32Plane + c];
+      const double rho = u[CW_RHO], tr2 = u[CW_TR2];
+      if (null_walk) {
+        // l_zero += trap r^2 (psi_l rho'_r tea - (rho psi_l + p_l) xi_r adtea / x)
+        acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * u[CW_TEA]), tr[4 * kCp32Plane + c], acc[7], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(-(tr2 * ((u[CW_RX] * u[CW_ADTEA]) * (rho * lpsi + lp))), rxr, acc[7], 0, 0, 0);
+        continue;
+      }
+      const double rxh = tr[1 * kCp32Plane + c], rtp = tr[2 * kCp32Plane + c], rtn = tr[3 * kCp32Plane + c], rrho = tr[4 * kCp32Plane + c];
+      const double eb = u[CW_EB], mrot = u[CW_MROT], c1 = u[CW_C1];
+      {
+        const double vol = u[CW_VOL];
+        const double c_rr = ipr * u[CW_U1] + q2x2 * u[CW_U3], c_hh = iph * u[CW_U2] + q2hx2 * eb;
+        const double adr = vol * (lxr * c_rr + lxh * (eb * q2_hld)), adh = vol * (lxh * c_hh + lxr * (eb * q2_hrd));
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(adr, rxr, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(adh, rxh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * adr, rxr, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1 * adh, rxh, acc[1], 0, 0, 0);
+        const double c2 = u[CW_C2];
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(c2 * adr, rxr, acc[2], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(c2 * adh, rxh, acc[2], 0, 0, 0);
+        // l_zero, the terms with F and F^2 of (sig rho) (sig (ipr rr + iph hh) + c1 ipr (s + hh)), sig = F - mrot
+        const double tw = tr2 * rho, ci = c1 * ipr, m2 = -2.0 * mrot;
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxr * (m2 * ipr) + lxh * ci), rxr, acc[3], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxh * (m2 * iph + ci) + lxr * ci), rxh, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxr * ipr), rxr, acc[4], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(tw * (lxh * iph), rxh, acc[4], 0, 0, 0);
+      }
+      {
+        const double vol2 = u[CW_VOL2], vrot = u[CW_VOL2ROT];
+        const double c_s = ipr * u[CW_U4] + q2 * u[CW_U5], c_h2 = ipr * u[CW_U2] + k6x2 * eb;
+        const double bs = mrot * (vol2 * c_s), bh2 = mrot * (vol2 * c_h2);
+        const double arr = lxh * bs, arh = lxr * bs + lxh * bh2;
+        const double atp = vrot * (lxr * q_rt_p + lxh * q_ht_p), atn = vrot * (lxr * q_rt_n + lxh * q_ht_n);
+        acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(arr, rxr, acc[5], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(arh, rxh, acc[5], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(atp, rtp, acc[5], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(atn, rtn, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * arr, rxr, acc[6], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * arh, rxh, acc[6], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * atp, rtp, acc[6], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrot * atn, rtn, acc[6], 0, 0, 0);
+        // l_zero, the terms without F
+        const double ca = u[CW_ADTEA] + q2 * u[CW_ADTEB], cb = u[CW_TEA] + q2 * u[CW_TEB], rx = u[CW_RX];
+        const double pp = rho * lpsi, mc = mrot * (c1 * ipr), mm = mrot * mrot;
+        const double a0r = tr2 * (rho * (lxr * (mm * ipr) - lxh * mc) - (rx * ca) * (pp + lp));
+        const double a0h = tr2 * (rho * (lxh * (mm * iph - mc) - lxr * mc) + (rx * (u[CW_TEB] * q2_hrd)) * (pp - lp));
+        acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0r, rxr, acc[7], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0h, rxh, acc[7], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr2 * (lpsi * cb), rrho, acc[7], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the grid's end land in this workgroup's LDS
+  if (!exists) return;
+  const size_t mm2 = M * M;
+  const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
+  const double F = a.freq[rj >= 0 ? rj : 0];
+  bool ok = true;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int li = a.order[l0 + (size_t)((lane >> 4) + 4 * v)];
+    if (rj < 0 || li < 0) continue;
+    const size_t at = size_t(li) + size_t(rj) * M;
+    if (null_walk) {
+      a.out[0 * mm2 + at] = 0.0; a.out[1 * mm2 + at] = 0.0; a.out[2 * mm2 + at] = 0.0;
+      a.out[3 * mm2 + at] = 0.0; a.out[4 * mm2 + at] = 0.0;
+      a.out[5 * mm2 + at] = acc[7][v];
+      ok = ok && isfinite(acc[7][v]);
+    } else {
+      const double lz = acc[7][v] + F * (acc[3][v] + F * acc[4][v]);
+      a.out[0 * mm2 + at] = acc[0][v]; a.out[1 * mm2 + at] = acc[1][v]; a.out[2 * mm2 + at] = acc[2][v];
+      a.out[3 * mm2 + at] = acc[5][v]; a.out[4 * mm2 + at] = acc[6][v];
+      a.out[5 * mm2 + at] = lz;
+      ok = ok && isfinite(acc[0][v]) && isfinite(acc[5][v]) && isfinite(lz);
+    }
+  }
+  if (!ok) atomicOr(a.flags, 1);
 }
 #endif
 
@@ -377,13 +586,6 @@ PDEV void coupling_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r)
   // same argument a block of such pairs skips the products that contain them (about a quarter of the instructions).
   const bool off_diag = ipr == 0.0 && iph == 0.0 && q_rt_p == 0.0 && q_rt_n == 0.0 && q_ht_p == 0.0 && q_ht_n == 0.0;
   const bool tame_block = a.tame != nullptr && a.weights_tame && __all(a.tame[lm] != 0 && a.tame[rm] != 0);
-#ifdef STORM_FAST_BUILD
-  if constexpr (TILE == 16) {
-    // FMA build: tiles of like degrees belong to the matrix-pipe walk (coupling_matrix_body, a launch of its own with
-    // its own, deeper staging ring -- inside this kernel the ring's LDS cost the vector walks half their occupancy)
-    if (cp_matrix_tile(a, l0, r0, lane).take) return;
-  }
-#endif
   // The walk of this WAVE's 8 x 8 block (wave-uniform): 0 = all factors zero, 1 = different degrees, 2 = the reference's
   // expression term by term, 3 = block outside the matrix (stages its share, no arithmetic).
   enum { kNull = 0, kOffDiag = 1, kFull = 2, kDead = 3 };
@@ -627,58 +829,74 @@ __global__ __launch_bounds__(64 * CpGeom<TILE>::kWaves, TILE == 16 ? STORM_CP_MI
   coupling_body<TILE>(a, blockIdx.x, blockIdx.y);
 }
 #ifdef STORM_FAST_BUILD
-// The tiles of like degrees (cp_matrix_tile): same grids as the kernels above, which leave those tiles alone.
-__global__ __launch_bounds__(256, 2) void coupling_matrix_kernel(CouplingArgs a) { coupling_matrix_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const CouplingArgs* __restrict__ table) {
-  const CouplingArgs a = table[blockIdx.z];
-  const size_t tiles = (a.n_modes + 15) / 16;
-  if (blockIdx.x >= tiles || blockIdx.y >= tiles) return;
-  coupling_matrix_body(a, blockIdx.x, blockIdx.y);
+// The matrix-pipe walk over the ordered mode list: ceil(n_pad / TILE)^2 tiles per problem.
+// Which tile a workgroup takes.  Workgroups go to the chip's 8 XCDs round-robin in launch order (workgroup L runs on XCD
+// L % 8) and every XCD has an L2 of its own, so the tiles one XCD works on at a time should share their modes: the tiles
+// are numbered super-tile by super-tile (8 x 8 tiles: the 64 workgroups of one read 8 left and 8 right sides between them
+// instead of 64 of each) and every XCD takes a contiguous eighth of that order.  With blockIdx.x = left tile, as before,
+// the 8 workgroups that share a right side sat on 8 different XCDs (M = 1024, 32 x 32 tiles: 4.3 GB fetched; 1.6 GB with
+// this order, profiles/r03_pmc_coupling_matrix.txt).
+constexpr unsigned kCpXcds = 8, kCpSuper = 8;
+// Tile number q of the T x T grid in super-tile-major order (rows of super-tiles top to bottom, the super-tiles of a row
+// left to right, the tiles of a super-tile column by column); the grid's last row and column of super-tiles may be narrower.
+PDEV void cp_tile_at(unsigned q, unsigned T, unsigned& tl, unsigned& tr) {
+  const unsigned S = (T + kCpSuper - 1) / kCpSuper;
+  const unsigned si = min(q / (kCpSuper * T), S - 1), h = min(kCpSuper, T - kCpSuper * si);
+  const unsigned r = q - si * kCpSuper * T;
+  const unsigned sj = min(r / (h * kCpSuper), S - 1), w = min(kCpSuper, T - kCpSuper * sj);
+  const unsigned r2 = r - sj * h * kCpSuper;
+  tl = kCpSuper * si + r2 % h;
+  tr = kCpSuper * sj + r2 / h;
+  (void)w;
 }
-#endif
-#ifdef STORM_FAST_BUILD
-// The two launches write disjoint tiles, and the vector walk of the few tiles that straddle degrees is a latency-bound
-// tail of milliseconds (one wave walks the grid point by point): the matrix launch goes to a side stream -- one per
-// device, created at first use and kept -- forked from and joined to the caller's stream by two events of this call, so
-// that both run at once (M = 1024, two degrees: 9.5 ms + 7.9 ms one after the other).
-hipStream_t cp_side_stream() {
-  static std::mutex mu;
-  static hipStream_t side[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!side[dev] && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) side[dev] = nullptr;
-  return side[dev];
+// XCD `xcd` of n_xcd takes a contiguous, equal share of that order (so its 64 resident workgroups work on one or two
+// super-tiles at a time, and every XCD gets the same number of tiles to within one); k = the workgroup's number on its XCD.
+PDEV bool cp_tile_of(unsigned xcd, unsigned k, unsigned n_xcd, unsigned T, unsigned& tl, unsigned& tr) {
+  const unsigned n = T * T, share = (n + n_xcd - 1) / n_xcd;
+  const unsigned q = xcd * share + k;
+  if (k >= share || q >= n) return false;
+  cp_tile_at(q, T, tl, tr);
+  return true;
 }
-// Runs `launch_side(stream)` beside what the caller puts on `main` between fork and join.
-struct CpFork {
-  hipStream_t main, side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  explicit CpFork(hipStream_t m) : main(m) {
-    side = cp_side_stream();
-    if (side && (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-                 hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess ||
-                 hipEventRecord(fork, main) != hipSuccess || hipStreamWaitEvent(side, fork, 0) != hipSuccess))
-      side = nullptr;  // (then everything stays on the caller's stream)
-  }
-  hipStream_t stream() const { return side ? side : main; }
-  hipError_t finish() {
-    hipError_t e = hipSuccess;
-    if (side) {
-      e = hipEventRecord(join, side);
-      if (e == hipSuccess) e = hipStreamWaitEvent(main, join, 0);
-    }
-    if (fork) (void)hipEventDestroy(fork);  // (destruction is deferred until the event has completed)
-    if (join) (void)hipEventDestroy(join);
-    fork = join = nullptr;
-    return e;
-  }
-};
+inline unsigned cp_grid_single(unsigned T) {  // workgroups of a one-problem launch
+  return (T * T + kCpXcds - 1) / kCpXcds * kCpXcds;
+}
+inline unsigned cp_per_problem(unsigned T) { return T * T; }  // workgroups per problem of a batch launch (a problem stays on one XCD)
+template <int TILE>
+PDEV void coupling_matrix_dispatch(const CouplingArgs& a, unsigned tl, unsigned tr) {
+  if constexpr (TILE == 16) coupling_matrix_body(a, tl, tr);
+  else coupling_matrix32_body(a, tl, tr);
+}
+template <int TILE>
+__global__ __launch_bounds__(256, 2) void coupling_matrix_kernel(CouplingArgs a) {
+  unsigned tl, tr;
+  if (!cp_tile_of(blockIdx.x % kCpXcds, blockIdx.x / kCpXcds, kCpXcds, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
+  coupling_matrix_dispatch<TILE>(a, tl, tr);
+}
+// several problems: problem p runs on XCD p % 8 (its modes are read by no other problem), per_problem workgroups each
+template <int TILE>
+__global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const CouplingArgs* __restrict__ table, unsigned n_problems,
+                                                                       unsigned per_problem) {
+  const unsigned xcd = blockIdx.x % kCpXcds, k = blockIdx.x / kCpXcds;
+  const unsigned p = (k / per_problem) * kCpXcds + xcd;
+  if (p >= n_problems) return;
+  const CouplingArgs a = table[p];
+  unsigned tl, tr;
+  if (!cp_tile_of(0, k % per_problem, 1, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
+  coupling_matrix_dispatch<TILE>(a, tl, tr);
+}
+// 32 x 32 tiles from this many workgroups on (one per CU and a few more): below, the 16 x 16 walk's four times as many
+// smaller workgroups fill the chip better.  0 < `force` = 16 or 32 overrides (option "coupling_matrix_tile").
+inline bool cp_use_tiles32(size_t tiles32_total, int force) {
+  if (force == 16) return false;
+  if (force == 32) return true;
+  return tiles32_total >= 384;
+}
 #endif
 }  // namespace
 
 hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
-                                 hipStream_t stream, bool with_tame, int tile) {
+                                 hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile) {
   if (n_problems == 0 || max_modes == 0) return hipSuccess;
   if (tile != 8 && tile != 16) return hipErrorInvalidValue;
   const unsigned tiles = (unsigned)((max_modes + tile - 1) / tile);
@@ -694,22 +912,29 @@ hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, s
     if (e != hipSuccess) return e;
   }
 #ifdef STORM_FAST_BUILD
-  if (tile == 16) {
-    CpFork fk(stream);  // (after the prepasses: both launches read their results)
-    coupling_matrix_batch_kernel<<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, fk.stream()>>>(table);
-    hipError_t e = hipGetLastError();
-    coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
-    if (e == hipSuccess) e = hipGetLastError();
-    const hipError_t j = fk.finish();
-    return e != hipSuccess ? e : j;
+  if (max_pad) {  // every entry carries an ordered mode list: the matrix-pipe walk takes all tiles
+    const unsigned ptiles = (unsigned)(max_pad / 16), ptiles32 = (unsigned)((max_pad + 31) / 32);
+    if (ptiles > 65535) return hipErrorInvalidValue;
+    const unsigned rounds = (unsigned)((n_problems + kCpXcds - 1) / kCpXcds);   // problems per XCD
+    if (cp_use_tiles32(size_t(ptiles32) * ptiles32 * n_problems, matrix_tile)) {
+      const unsigned per = cp_per_problem(ptiles32);
+      coupling_matrix_batch_kernel<32><<<dim3(rounds * per * kCpXcds, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per);
+    } else {
+      const unsigned per = cp_per_problem(ptiles);
+      if (size_t(rounds) * per * kCpXcds > 0x7fffffffu) return hipErrorInvalidValue;
+      coupling_matrix_batch_kernel<16><<<dim3(rounds * per * kCpXcds, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per);
+    }
+    return hipGetLastError();
   }
+#else
+  (void)max_pad; (void)matrix_tile;
 #endif
   if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
   else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);
   return hipGetLastError();
 }
 
-hipError_t launch_coupling(const CouplingArgs& a, int tile) {
+hipError_t launch_coupling(const CouplingArgs& a, int tile, int matrix_tile) {
   if (a.n_modes == 0) return hipSuccess;
   if (a.n_pts < 2 || (tile != 8 && tile != 16)) return hipErrorInvalidValue;
   const unsigned tiles = (unsigned)((a.n_modes + tile - 1) / tile);
@@ -725,15 +950,15 @@ hipError_t launch_coupling(const CouplingArgs& a, int tile) {
     if (e != hipSuccess) return e;
   }
 #ifdef STORM_FAST_BUILD
-  if (tile == 16) {
-    CpFork fk(a.stream);
-    coupling_matrix_kernel<<<dim3(tiles, tiles, 1), 256, 0, fk.stream()>>>(a);
-    hipError_t e = hipGetLastError();
-    coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);
-    if (e == hipSuccess) e = hipGetLastError();
-    const hipError_t j = fk.finish();
-    return e != hipSuccess ? e : j;
+  if (a.order) {  // the matrix-pipe walk over the ordered mode list takes all tiles
+    const unsigned ptiles = (unsigned)(a.n_pad / 16), ptiles32 = (unsigned)((a.n_pad + 31) / 32);
+    if (a.n_pad % 16 || ptiles == 0 || ptiles > 65535) return hipErrorInvalidValue;
+    if (cp_use_tiles32(size_t(ptiles32) * ptiles32, matrix_tile)) coupling_matrix_kernel<32><<<dim3(cp_grid_single(ptiles32), 1, 1), 256, 0, a.stream>>>(a);
+    else coupling_matrix_kernel<16><<<dim3(cp_grid_single(ptiles), 1, 1), 256, 0, a.stream>>>(a);
+    return hipGetLastError();
   }
+#else
+  (void)matrix_tile;
 #endif
   if (tile == 8) coupling_kernel<8><<<dim3(tiles, tiles, 1), 64, 0, a.stream>>>(a);
   else coupling_kernel<16><<<dim3(tiles, tiles, 1), 256, 0, a.stream>>>(a);

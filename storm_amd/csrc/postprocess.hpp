@@ -100,6 +100,11 @@ struct CouplingArgs {
   // below 2^200 in magnitude), nullptr = never take the shortcut; weights_tame: the same property of `weights` (host).
   int* tame = nullptr;
   int weights_tame = 0;
+  // FMA build, matrix-pipe walk: the problem's modes grouped by degree, every group padded to a multiple of 16 positions;
+  // device [n_pad], order[pos] = index into the arrays above (0 .. n_modes - 1) or -1 for padding; a tile's first position
+  // is never padding.  nullptr: the vector walk (always in the parity build).
+  const int* order = nullptr;
+  size_t n_pad = 0;
 };
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
@@ -113,12 +118,14 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
 // storm_fast = FMA contraction allowed).  launch_coupling_batch: several coupling problems in one launch, blockIdx.z
 // picks table[z] (device array; args.stream is ignored); max_modes = the largest n_modes in the table, n_pts = the
 // (common) grid size of the entries; with_tame: some entry has a `tame` array to fill first.  tile: modes per side of a
-// workgroup's tile of pairs, 8 (one wave) or 16 (four waves sharing the staged fields).
+// workgroup's tile of pairs, 8 (one wave) or 16 (four waves sharing the staged fields).  max_pad: the largest n_pad of
+// the table if EVERY entry carries an ordered mode list (FMA build: the matrix-pipe walk takes the launch), else 0;
+// matrix_tile: 0 = automatic, 16 or 32 = that tile of the matrix-pipe walk.
 #define STORM_DECL_COUPLING(ns)                                                                                         \
   namespace ns {                                                                                                        \
-  hipError_t launch_coupling(const storm::CouplingArgs& args, int tile);                                                \
+  hipError_t launch_coupling(const storm::CouplingArgs& args, int tile, int matrix_tile);                               \
   hipError_t launch_coupling_batch(const storm::CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts, \
-                                   hipStream_t stream, bool with_tame, int tile);                                       \
+                                   hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile);      \
   }
 STORM_DECL_COUPLING(storm)
 STORM_DECL_COUPLING(storm_fast)

@@ -248,7 +248,7 @@ struct storm_postproc {
   DevBuf<double> d_freq, d_vec, d_terms, d_scale, d_fields, d_nodes;
   DevBuf<long long> d_ids;
   DevBuf<double> d_weights, d_consts, d_out;  // coupling integrals
-  DevBuf<int> d_ell_index, d_cflags;
+  DevBuf<int> d_ell_index, d_cflags, d_order;
   DevBuf<long long> d_gather;                 // rows to pick out of a sweep's resident fields
   hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the coupling kernel
   std::vector<double> h_r, h_rho, h_rot, h_trap;  // host copies of the planes the coupling weights are built from
@@ -258,6 +258,8 @@ struct storm_postproc {
   double last_coupling_ms = 0.0;       // HIP-event duration of the last coupling kernel
   int arith = 0;                       // coupling integrals: 0 = the reference's association, 1 = FMA build (option "arithmetic")
   int cp_tile = 0;                     // modes per side of a workgroup's tile of pairs: 0 = automatic, 8, 16 (option "coupling_tile")
+  int cp_matrix = 1;                   // FMA build: 1 = the matrix-pipe walk over the ordered mode list, 0 = the vector walk (option "coupling_matrix")
+  int cp_matrix_tile = 0;              // its tile: 0 = automatic, 16, 32 (option "coupling_matrix_tile")
   std::mutex mu;
 };
 
@@ -1368,7 +1370,7 @@ void storm_postproc_destroy(storm_postproc* p) {
   p->h_model.release();
   p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
   p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
-  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release(); p->d_gather.release();
+  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release(); p->d_order.release(); p->d_gather.release();
   (void)hipSetDevice(prev);
   delete p;
 }
@@ -1384,6 +1386,12 @@ int storm_postproc_set_option(storm_postproc* p, const char* key, int64_t value)
     } else if (k == "coupling_tile") {
       if (value != 0 && value != 8 && value != 16) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_tile must be 0 (auto), 8 or 16");
       p->cp_tile = int(value);
+    } else if (k == "coupling_matrix") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix must be 0 or 1");
+      p->cp_matrix = int(value);
+    } else if (k == "coupling_matrix_tile") {
+      if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix_tile must be 0 (auto), 16 or 32");
+      p->cp_matrix_tile = int(value);
     } else {
       fail(STORM_ERR_INVALID_ARGUMENT, "unknown option: " + k);
     }
@@ -1485,6 +1493,17 @@ size_t coupling_consts(size_t n, const uint64_t* ell, int64_t m, int* ell_index,
 
 // The kernel's shortcut for tiles whose Gaunt factors are all zero (coupling_kernels.hip, coupling_body) needs finite
 // operands of moderate size: the weights are checked here, the modes on the device.
+// The ordered mode list of the matrix-pipe walk (FMA build; CouplingArgs::order): the modes grouped by degree in order of
+// first appearance, the caller's order kept inside a group, every group padded with -1 to a multiple of 16 positions.
+inline void coupling_order(size_t n, const int* ell_index, size_t n_ell, std::vector<int>& order) {
+  order.clear();
+  for (size_t e = 0; e < n_ell; ++e) {
+    for (size_t k = 0; k < n; ++k)
+      if (size_t(ell_index[k]) == e) order.push_back(int(k));
+    while (order.size() % 16) order.push_back(-1);
+  }
+}
+
 // Tile of the coupling kernel when the handle's "coupling_tile" is 0: 16 (four waves share every staged chunk: half the
 // L2 fetches) once the matrix has enough pairs to fill the card either way, 8 below (more, smaller workgroups).
 inline int coupling_tile_auto(size_t max_modes) { return max_modes >= 192 ? 16 : 8; }
@@ -1556,6 +1575,9 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     p->d_ell_index.reserve(n, p->stream);
     p->d_out.reserve(size_t(kCouplingMatrices) * n * n, p->stream);
     p->d_cflags.reserve(1 + n, p->stream);  // [0]: non-finite flag, [1..]: per-mode "tame" flags (kernel scratch)
+    std::vector<int> order;
+    if (p->arith == 1 && p->cp_matrix) coupling_order(n, ell_index.data(), ne, order);
+    p->d_order.reserve(order.size() + 1, p->stream);
     hipStream_t st = post_stream(p);
     provide_fields(p->d_fields.p, st);
     hip_check(hipMemcpyAsync(p->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
@@ -1567,6 +1589,10 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
     a.rows = nullptr; a.stream = st;
+    if (!order.empty()) {
+      hip_check(hipMemcpyAsync(p->d_order.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st), "order H2D");
+      a.order = p->d_order.p; a.n_pad = order.size();
+    }
     if (coupling_has_sparse_pair(consts)) {
       a.tame = p->d_cflags.p + 1;
       a.weights_tame = coupling_weights_tame(w.data(), np * kCouplingWeights) ? 1 : 0;
@@ -1574,7 +1600,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
     if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
     hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
-    hip_check((p->arith ? storm_fast::launch_coupling : storm::launch_coupling)(a, p->cp_tile ? p->cp_tile : coupling_tile_auto(n)),
+    hip_check((p->arith ? storm_fast::launch_coupling : storm::launch_coupling)(a, p->cp_tile ? p->cp_tile : coupling_tile_auto(n), p->cp_matrix_tile),
               "coupling launch");
     hip_check(hipEventRecord(p->ev1, st), "hipEventRecord");
     // results through pinned memory (a copy to pageable memory takes the runtime's staged, host-synchronous path)
@@ -1815,7 +1841,7 @@ struct storm_sweep {
   std::vector<long long> resident_at;
   DevBuf<double> d_cp;        // batched coupling integrals: weights, consts, frequencies, results of every problem
   DevBuf<long long> d_cp_idx; // rows of the resident fields
-  DevBuf<int> d_cp_ell, d_cp_flags;
+  DevBuf<int> d_cp_ell, d_cp_flags, d_cp_order;
   DevBuf<CouplingArgs> d_cp_table;
   PinnedBuf h_cp;
   PinnedBuf h_in, h_out, h_flags;
@@ -1828,17 +1854,13 @@ struct storm_sweep {
   PinnedBuf h_growth;
   int segments = 0;           // option "segments": -1 = never, 0 = automatic (FMA build only)
   double seg_growth_max = 0x1p24;
-  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0;
-  // bracket refinement on the device (set_refine_device): states, live counters per round, flag word, pinned staging
-  // option "device_brackets": 0 (default) = state machine on the host, which evaluates only the brackets still open; 1 = on
-  // the device, every slot every round.  Measured (64 systems x 300 frequencies, 1688 brackets, 7 rounds, parity build):
-  // 17.8 ms per scan on the host, 20.2 ms on the device -- the late rounds of a sweep have a handful of open brackets, and
-  // a round over all 1900 slots costs more than the host round trip it saves.  (A single handle's default is the device.)
-  int device_brackets = 0;
-  DevBuf<BracketDev> d_br;
-  DevBuf<unsigned> d_live;
-  DevBuf<int> d_bflags;
-  PinnedBuf h_br;
+  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0, cp_matrix = 1, cp_matrix_tile = 0;
+  // (A sweep refines its brackets with the host state machine, set_refine: it evaluates only the brackets still open.  A
+  // device version over all bracket slots every round existed in round 2 behind an option and was removed in round 3: 64
+  // systems x 300 frequencies, 1688 brackets, 7 rounds: 17.8 ms per scan on the host, 20.2 ms on the device -- the late rounds
+  // have a handful of open brackets, and compacting them on the device would need the per-system, per-class padded
+  // layout of the discriminant launch rebuilt every round, i.e. the counts on the host, i.e. the round trip it was
+  // meant to save.  A single handle's brackets do run on the device: refine_device.)
   size_t steps_bytes_max = size_t(16) << 30;  // eigenvector staging per chunk (2 MB per mode at 6199 intervals)
   storm_stats stats{};
   std::mutex mu;
@@ -1991,96 +2013,6 @@ void set_refine(storm_sweep* q, std::vector<SetBracket>& br, uint64_t ulp) {
       else { b.previous = b.lower; b.lower = next; }
       b.has_prev = true;
     }
-  }
-}
-
-// The same with the state machine on the device (refine_step_kernel, as refine_device does for a single handle): every
-// bracket keeps ONE slot for the whole refinement -- a system's brackets padded to kSetPad slots with finished copies of its
-// last one, so that the launches see the layout set_det gives them -- and a round is evaluate (all slots: a finished
-// bracket re-evaluates its lower end, a few wasted chains instead of a host round trip) -> update -> propose, all in the
-// stream; only the live counters cross PCIe, every `batch` rounds.  Same proposals, same evaluations per bracket, same
-// end points, roots and evals as set_refine (the FMA build's segment path cuts by batch size, so there the discriminants
-// of a round agree to its tolerance contract, not to the bit).
-void set_refine_device(storm_sweep* q, std::vector<SetBracket>& br, uint64_t ulp) {
-  if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
-  if (!(ulp < (uint64_t(1) << 54))) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be < 2^54");
-  if (br.empty()) return;
-  const size_t S = q->n_sys;
-  std::vector<size_t> nb(S, 0), poff(S + 1, 0);
-  for (const SetBracket& b : br) nb[b.pos] += 1;
-  for (size_t k = 0; k < S; ++k) poff[k + 1] = poff[k] + (nb[k] + kSetPad - 1) / kSetPad * kSetPad;
-  const size_t total = poff[S];
-  if (total > (size_t(1) << 31)) fail(STORM_ERR_INVALID_ARGUMENT, "too many brackets in one call");
-  hipStream_t st = q->stream;
-  // pinned staging: [2 ints: flags][kMaxRounds + 2 live counters][slots: BracketDev][slots: int system position]
-  size_t bytes = 16 + (kMaxRounds + 2) * sizeof(unsigned);
-  bytes = (bytes + 15) / 16 * 16;
-  const size_t off_br = bytes;
-  bytes += total * sizeof(BracketDev);
-  const size_t off_sys = bytes;
-  bytes += total * sizeof(int);
-  if ((bytes + 7) / 8 > q->h_br.cap && q->h_br.p) sync_stream(st, q->sync_marker);
-  q->h_br.reserve((bytes + 7) / 8);
-  char* base = reinterpret_cast<char*>(q->h_br.p);
-  int* h_flags = reinterpret_cast<int*>(base);
-  unsigned* h_live = reinterpret_cast<unsigned*>(base + 16);
-  BracketDev* h_slots = reinterpret_cast<BracketDev*>(base + off_br);
-  int* h_sys = reinterpret_cast<int*>(base + off_sys);
-  std::vector<size_t> slot_of(br.size());
-  {
-    std::vector<size_t> at(poff.begin(), poff.end() - 1);
-    for (size_t j = 0; j < br.size(); ++j) {  // (br is sorted by system position)
-      const SetBracket& b = br[j];
-      BracketDev d{};
-      d.lo_x = b.lower.x; d.lo_f = b.lower.f; d.hi_x = b.upper.x; d.hi_f = b.upper.f;
-      slot_of[j] = at[b.pos];
-      h_slots[at[b.pos]++] = d;
-    }
-    for (size_t k = 0; k < S; ++k) {
-      for (size_t i = at[k]; i < poff[k + 1]; ++i) {  // padding: a finished copy of the system's last bracket
-        h_slots[i] = h_slots[at[k] - 1];
-        h_slots[i].done = 1;
-      }
-      for (size_t i = poff[k]; i < poff[k + 1]; ++i) h_sys[i] = int(k);
-    }
-  }
-  q->d_br.reserve(total, st); q->d_freq.reserve(total, st); q->d_det.reserve(total, st); q->d_sys.reserve(total, st);
-  q->d_live.reserve(kMaxRounds + 2, st); q->d_bflags.reserve(2, st);
-  hip_check(hipMemsetAsync(q->d_live.p, 0, (kMaxRounds + 2) * sizeof(unsigned), st), "live memset");
-  hip_check(hipMemsetAsync(q->d_bflags.p, 0, 2 * sizeof(int), st), "flags memset");
-  hip_check(hipMemcpyAsync(q->d_br.p, h_slots, total * sizeof(BracketDev), hipMemcpyHostToDevice, st), "brackets H2D");
-  hip_check(hipMemcpyAsync(q->d_sys.p, h_sys, total * sizeof(int), hipMemcpyHostToDevice, st), "system index H2D");
-  hip_check(storm::launch_refine_step(q->d_br.p, total, nullptr, q->d_freq.p, ulp, q->d_live.p, q->d_bflags.p, st), "refine_step launch");
-  q->stats.launches += 1;
-  // rounds between two looks at the live counters: cheap rounds (segment path) may be wasted, dear ones are not
-  const size_t batch = (set_uses_segments(q) && total <= kSetSegMaxBatch) ? 3 : 1;
-  size_t round = 0;  // live[r] = brackets that want evaluation r + 1
-  for (;;) {
-    if (round + batch > kMaxRounds) fail(STORM_ERR_BRACKET, "bracket refinement did not converge");
-    for (size_t b = 0; b < batch; ++b) {
-      set_det_launch(q, poff);
-      hip_check(storm::launch_refine_step(q->d_br.p, total, q->d_det.p, q->d_freq.p, ulp, q->d_live.p + round + 1, q->d_bflags.p, st),
-                "refine_step launch");
-      q->stats.launches += 1;
-      ++round;
-    }
-    hip_check(hipMemcpyAsync(h_live, q->d_live.p, (round + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st), "live D2H");
-    hip_check(hipMemcpyAsync(h_flags, q->d_bflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
-    set_check_flags(q);  // synchronises; singular stage matrices
-    raise_bracket_flags(*h_flags);
-    if (h_live[round] == 0) break;
-  }
-  for (size_t r = 0; r < round; ++r) {
-    q->stats.refine_rounds += h_live[r] > 0;
-    q->stats.refine_evals += h_live[r];
-    q->stats.det_evals += h_live[r];
-  }
-  hip_check(hipMemcpyAsync(h_slots, q->d_br.p, total * sizeof(BracketDev), hipMemcpyDeviceToHost, st), "brackets D2H");
-  sync_stream(st, q->sync_marker);
-  for (size_t j = 0; j < br.size(); ++j) {
-    const BracketDev& d = h_slots[slot_of[j]];
-    SetBracket& b = br[j];
-    b.lower = Pt{d.lo_x, d.lo_f}; b.upper = Pt{d.hi_x, d.hi_f}; b.root = d.root; b.evals = d.evals; b.done = true;
   }
 }
 
@@ -2359,10 +2291,9 @@ void storm_sweep_destroy(storm_sweep* q) {
   if (q->sync_marker) (void)hipEventDestroy(q->sync_marker);
   q->tab.release(); q->d_table.release(); q->d_freq.release(); q->d_det.release(); q->d_steps.release(); q->d_upper.release();
   q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
-  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release();
+  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release(); q->d_cp_order.release();
   q->d_cp_table.release(); q->h_cp.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
   q->d_partials.release(); q->d_seg_nodes.release(); q->d_growth.release(); q->d_table_red.release(); q->h_growth.release();
-  q->d_br.release(); q->d_live.release(); q->d_bflags.release(); q->h_br.release();
   (void)hipSetDevice(prev);
   delete q;
 }
@@ -2384,12 +2315,15 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "coupling_tile") {
       if (value != 0 && value != 8 && value != 16) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_tile must be 0 (auto), 8 or 16");
       q->cp_tile = int(value);
+    } else if (k == "coupling_matrix") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix must be 0 or 1");
+      q->cp_matrix = int(value);
+    } else if (k == "coupling_matrix_tile") {
+      if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix_tile must be 0 (auto), 16 or 32");
+      q->cp_matrix_tile = int(value);
     } else if (k == "segments") {
       if (value != 0 && value != -1) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be 0 (automatic, FMA build only) or -1 (never)");
       q->segments = int(value);
-    } else if (k == "device_brackets") {
-      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "device_brackets must be 0 (host state machine) or 1");
-      q->device_brackets = int(value);
     } else if (k == "seg_growth_log2") {
       if (value < 0 || value > 1000) fail(STORM_ERR_INVALID_ARGUMENT, "seg_growth_log2 must be 0 .. 1000");
       q->seg_growth_max = std::ldexp(1.0, int(value));
@@ -2490,8 +2424,7 @@ int storm_sweep_scan_and_optimize(storm_sweep* q, const size_t* freq_offsets, co
     }
     for (size_t u = 0; u < S; ++u) out_offsets[u + 1] = out_offsets[u] + n_br[u];
     if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
-    if (q->device_brackets) set_refine_device(q, br, ulp);
-    else set_refine(q, br, ulp);
+    set_refine(q, br, ulp);
     std::vector<size_t> at(out_offsets, out_offsets + S);
     for (size_t j = 0; j < br.size(); ++j) {
       const size_t u = q->order[br[j].pos], dst = at[u]++;
@@ -2734,9 +2667,25 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     std::vector<CouplingArgs> table(n_problems);
     size_t out_at = 0;
     bool with_tame = false;
+    // FMA build: every problem's ordered mode list (matrix-pipe walk), back to back in one device array
+    std::vector<int> orders, one;
+    std::vector<size_t> ord_off(n_problems + 1, 0);
+    size_t max_pad = 0;
+    if (q->arith == 1 && q->cp_matrix) {
+      for (size_t j = 0; j < n_problems; ++j) {
+        const size_t n = offsets[j + 1] - offsets[j];
+        coupling_order(n, ell_index.data() + offsets[j], n_ell[j], one);
+        orders.insert(orders.end(), one.begin(), one.end());
+        ord_off[j + 1] = orders.size();
+        max_pad = std::max(max_pad, one.size());
+      }
+      q->d_cp_order.reserve(orders.size() + 1, st);
+      hip_check(hipMemcpyAsync(q->d_cp_order.p, orders.data(), orders.size() * sizeof(int), hipMemcpyHostToDevice, st), "order H2D");
+    }
     for (size_t j = 0; j < n_problems; ++j) {
       const size_t n = offsets[j + 1] - offsets[j];
       CouplingArgs& a = table[j];
+      if (max_pad) { a.order = q->d_cp_order.p + ord_off[j]; a.n_pad = ord_off[j + 1] - ord_off[j]; }
       a.n_pts = np; a.n_modes = n; a.fields = q->d_fields.p; a.rows = q->d_cp_idx.p + offsets[j];
       a.freq = df + offsets[j]; a.ell_index = q->d_cp_ell.p + offsets[j];
       a.consts = dc + c_off[j]; a.n_ell = int(n_ell[j]); a.weights = dw + j * w_elems;
@@ -2755,7 +2704,7 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
     hip_check((q->arith ? storm_fast::launch_coupling_batch : storm::launch_coupling_batch)(q->d_cp_table.p, n_problems,
                                                                                              max_modes, np, st, with_tame,
-                                                                                             q->cp_tile ? q->cp_tile : coupling_tile_auto(max_modes)),
+                                                                                             q->cp_tile ? q->cp_tile : coupling_tile_auto(max_modes), max_pad, q->cp_matrix_tile),
               "coupling launch");
     q->stats.launches += 1;
     // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the

@@ -245,16 +245,46 @@ def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
     # two-instruction form) -- m = 1 and rotation, so every weight and every power of the frequency is in play.  The FMA
     # build's contract: 1e-12 of each matrix's largest magnitude (another association of the sum over the grid).
     post.set_option("arithmetic", 1)
-    for tile in (16, 8):
+    # the matrix-pipe walk with 16 x 16 and 32 x 32 tiles (3 blocks of 16 per side: the second 32-tile's last block does not
+    # exist), then the vector walks
+    for matrix, tile, mtile in ((1, 0, 16), (1, 0, 32), (0, 16, 0), (0, 8, 0)):
+        post.set_option("coupling_matrix", matrix)
         post.set_option("coupling_tile", tile)
+        post.set_option("coupling_matrix_tile", mtile)
         fast = post.coupling_matrices(ell, freq, fields, 1, metric)
         for k in storm_amd.COUPLING_MATRICES:
             scale = np.max(np.abs(got[k]))
             assert scale > 0.0, k
-            assert np.max(np.abs(fast[k] - got[k])) <= 1e-12 * scale, (k, tile, np.max(np.abs(fast[k] - got[k])) / scale)
+            assert np.max(np.abs(fast[k] - got[k])) <= 1e-12 * scale, (k, matrix, tile, mtile, np.max(np.abs(fast[k] - got[k])) / scale)
         far16 = np.abs(ell[:, None].astype(int) - ell[None, :].astype(int)) > 2
         for k in ("d_squared", "d_linear", "d_zero", "r_linear", "r_zero"):
             assert np.all(fast[k][far16] == 0.0) and not np.any(np.signbit(fast[k][far16])), (k, tile)
+    post.set_option("coupling_matrix", 1)
+    post.set_option("coupling_tile", 0)
+    # The matrix-pipe walk on modes in ANY order and number: the library groups them by degree and pads every group to a
+    # multiple of 16 positions (CouplingArgs::order), so ragged groups (12, 16 and 7 modes) in shuffled order exercise the
+    # permutation on the way in (staging rows, frequencies, tame flags) and on the way out (padding stores nothing).
+    rng = np.random.default_rng(5)
+    pick = np.concatenate([np.arange(12), 16 + np.arange(16), 32 + np.arange(7)])
+    pick = pick[rng.permutation(pick.size)]
+    e2, f2, fl2 = ell[pick], freq[pick], np.ascontiguousarray(fields[pick])
+    ref2, _ = model.coupling_matrices(e2, f2, fl2, 1, metric, threads=16)
+    far2 = np.abs(e2[:, None].astype(int) - e2[None, :].astype(int)) > 2
+    mid2 = fl2.copy()
+    mid2[3] *= 2.0 ** 150          # (2^150 is tame, 2^300 is not)
+    ref3, _ = model.coupling_matrices(e2, f2, mid2, 1, metric, threads=16)
+    for mtile in (16, 32):
+        post.set_option("coupling_matrix_tile", mtile)
+        fast2 = post.coupling_matrices(e2, f2, fl2, 1, metric)
+        for k in storm_amd.COUPLING_MATRICES:
+            scale = np.max(np.abs(ref2[k]))
+            assert np.max(np.abs(fast2[k] - ref2[k])) <= 1e-12 * scale, (k, mtile, np.max(np.abs(fast2[k] - ref2[k])) / scale)
+            if k != "l_zero":
+                assert np.all(fast2[k][far2] == 0.0) and not np.any(np.signbit(fast2[k][far2])), (k, mtile)
+        fast3 = post.coupling_matrices(e2, f2, mid2, 1, metric)
+        for k in storm_amd.COUPLING_MATRICES:
+            assert np.max(np.abs(fast3[k] - ref3[k])) <= 1e-12 * np.max(np.abs(ref3[k])), (k, mtile)
+    post.set_option("coupling_matrix_tile", 0)
     post.set_option("arithmetic", 0)
     # 12 modes per degree: the 16 x 16 tiles straddle the degree blocks, so the four waves of one workgroup take
     # different walks (all factors zero / different degrees / full expression) around the same staged chunks

@@ -80,18 +80,6 @@ def test_sweep_scan_bit_exact(oracle, golden_dir, scheme):
     assert n_modes > 10
     st = sweep.stats()
     assert st["refine_rounds"] > 0 and st["refine_evals"] == sum(b["evals"] for br, _, _ in got for b in br)
-    # the bracket state machine on the device (option device_brackets = 1; a sweep's default is the host one, which
-    # evaluates only the brackets still open): same brackets, same counters (InverseQuadratic::optimize,
-    # src/bracket.rs:148-223, either way)
-    sweep.set_option("device_brackets", 1)
-    sweep.stats(reset=True)
-    on_device = sweep.scan_and_optimize(grids, ulp)
-    for k in range(len(solvers)):
-        assert same_brackets(on_device[k][0], got[k][0]) and on_device[k][2] == got[k][2], (scheme, k, "device state machine")
-    st_dev = sweep.stats()
-    assert (st_dev["refine_rounds"], st_dev["refine_evals"]) == (st["refine_rounds"], st["refine_evals"]), (st_dev, st)
-    assert st_dev["det_evals"] == sum(g.size for g in grids) + st_dev["refine_evals"]
-    sweep.set_option("device_brackets", 0)
     if scheme in ("colloc4", "magnus2"):
         # eigenvectors of every mode of every system in one pass
         roots = [np.array([b["root"] for b in br]) for br, _, _ in got]
