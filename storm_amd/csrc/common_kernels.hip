@@ -198,9 +198,40 @@ __global__ __launch_bounds__(kSwapBlock) void swap_count_kernel(const double* __
   }
 }
 
-// block_offset[b] = number of brackets before block b (host-side exclusive sum of the block counts).
+// The exclusive sum of the block counts, in place, by ONE workgroup (a scan has n / 1024 blocks: 98 for 10^5 points); the
+// total goes to block_count[n_blocks].  On the device so that count -> offsets -> emit is one stream of launches: round 2
+// summed on the host, a D2H copy, a synchronisation and an H2D copy in the middle of every scan.
+__global__ __launch_bounds__(kSwapBlock) void swap_offsets_kernel(unsigned* __restrict__ block_count, unsigned n_blocks) {
+  __shared__ unsigned sh[kSwapBlock];
+  __shared__ unsigned carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < n_blocks; base += kSwapBlock) {
+    const unsigned k = base + threadIdx.x;
+    const unsigned cnt = k < n_blocks ? block_count[k] : 0;
+    sh[threadIdx.x] = cnt;
+    __syncthreads();
+    unsigned incl = cnt;
+    for (int d = 1; d < kSwapBlock; d <<= 1) {
+      const unsigned add = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      incl += add;
+      sh[threadIdx.x] = incl;
+      __syncthreads();
+    }
+    const unsigned before = carry;
+    if (k < n_blocks) block_count[k] = before + incl - cnt;
+    __syncthreads();
+    if (threadIdx.x == kSwapBlock - 1) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_count[n_blocks] = carry;
+}
+
+// block_offset[b] = number of brackets before block b (swap_offsets_kernel).  Brackets from position `cap` on are not
+// written (the caller learns the total from the offsets and reports the overflow).
 __global__ __launch_bounds__(kSwapBlock) void swap_emit_kernel(const double* __restrict__ freq, const double* __restrict__ det,
-                                                               size_t n, const unsigned* __restrict__ block_offset,
+                                                               size_t n, const unsigned* __restrict__ block_offset, size_t cap,
                                                                BracketDev* __restrict__ out, unsigned long long* __restrict__ index_out) {
   __shared__ unsigned sh[kSwapBlock];
   const size_t first = ((size_t)blockIdx.x * kSwapBlock + threadIdx.x) * kSwapPer;
@@ -225,7 +256,8 @@ __global__ __launch_bounds__(kSwapBlock) void swap_emit_kernel(const double* __r
   size_t at = (size_t)block_offset[blockIdx.x] + (incl - cnt);
 #pragma unroll
   for (int j = 0; j < kSwapPer; ++j)
-    if (kind[j] == 1) {
+    if (kind[j] == 1 && at >= cap) ++at;
+    else if (kind[j] == 1) {
       const size_t i = first + j;
       BracketDev b;
       b.lo_x = freq[i]; b.lo_f = det[i]; b.hi_x = freq[i + 1]; b.hi_f = det[i + 1];
@@ -327,10 +359,14 @@ hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count,
   swap_count_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(det, n, block_count, flags);
   return hipGetLastError();
 }
-hipError_t launch_swap_emit(const double* freq, const double* det, size_t n, const unsigned* block_offset, BracketDev* out,
+hipError_t launch_swap_offsets(unsigned* block_count, size_t n_blocks, hipStream_t stream) {
+  swap_offsets_kernel<<<1, kSwapBlock, 0, stream>>>(block_count, (unsigned)n_blocks);
+  return hipGetLastError();
+}
+hipError_t launch_swap_emit(const double* freq, const double* det, size_t n, const unsigned* block_offset, size_t cap, BracketDev* out,
                             unsigned long long* index_out, hipStream_t stream) {
   if (n < 2) return hipSuccess;
-  swap_emit_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(freq, det, n, block_offset, out, index_out);
+  swap_emit_kernel<<<(unsigned)swap_blocks(n), kSwapBlock, 0, stream>>>(freq, det, n, block_offset, cap, out, index_out);
   return hipGetLastError();
 }
 hipError_t launch_refine_step(BracketDev* br, size_t n, const double* f_in, double* x_out, unsigned long long ulp,

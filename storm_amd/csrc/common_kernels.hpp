@@ -28,8 +28,9 @@ inline size_t swap_blocks(size_t n) { return n < 2 ? 0 : (n - 1 + 1023) / 1024; 
                                  const double* steps, double* mantissa_out, long long* exponent_out, hipStream_t stream); \
   hipError_t launch_aos_copy(double* tab, size_t n_sys, size_t sys_elems, size_t stride, int p, hipStream_t stream); \
   hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count, int* flags, hipStream_t stream); \
+  hipError_t launch_swap_offsets(unsigned* block_count, size_t n_blocks, hipStream_t stream);                      \
   hipError_t launch_swap_emit(const double* freq, const double* det, size_t n, const unsigned* block_offset,       \
-                              storm::BracketDev* out, unsigned long long* index_out, hipStream_t stream);          \
+                              size_t cap, storm::BracketDev* out, unsigned long long* index_out, hipStream_t stream); \
   hipError_t launch_refine_step(storm::BracketDev* br, size_t n, const double* f_in, double* x_out,                \
                                 unsigned long long ulp, unsigned* live_out, int* flags, hipStream_t stream);       \
   bool eigen_uses_lanes(size_t n, int layout);                                                                    \

@@ -16,6 +16,7 @@
 #pragma once
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -79,11 +80,20 @@ void multi_scan_and_optimize(const std::vector<typename Ops::Solver>& solvers, c
     p.lo = lo;
     const size_t m = std::min(hi + 1, n) - lo;  // with the halo
     if (hi == lo) return int(STORM_OK);
-    p.br.resize(m); p.idx.resize(m);
+    // room for 8192 brackets first (a scan finds a few dozen); only if a slice has more is the scan repeated with room
+    // for one per grid point (zero-filling 56 B per grid point on every call cost 1 ms per 10^5 points)
+    size_t room = std::min<size_t>(m, 8192);
+    p.br.resize(room); p.idx.resize(room);
     if (det_out) p.det.resize(m);
     size_t found = 0;
-    const int rc = Ops::scan_brackets(solvers[k], freq + lo, m, p.br.data(), m, &found, &p.invalid,
-                                      det_out ? p.det.data() : nullptr, p.idx.data());
+    int rc = Ops::scan_brackets(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid,
+                                det_out ? p.det.data() : nullptr, p.idx.data());
+    if (rc == STORM_ERR_CAPACITY && room < m) {
+      room = m;
+      p.br.resize(room); p.idx.resize(room);
+      rc = Ops::scan_brackets(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid,
+                              det_out ? p.det.data() : nullptr, p.idx.data());
+    }
     p.br.resize(rc == STORM_OK ? found : 0); p.idx.resize(rc == STORM_OK ? found : 0);
     if (rc == STORM_OK && det_out) std::memcpy(det_out + lo, p.det.data(), (hi - lo) * sizeof(double));  // owned points only
     return rc;
@@ -117,15 +127,22 @@ void multi_eigenvector_batch(const std::vector<typename Ops::Solver>& solvers, c
                              double* vec_out) {
   if (n == 0) return;
   const size_t D = solvers.size(), len = (Ops::n_int(solvers[0]) + 1) * 4;
+  if (D == 1) {  // one device: straight into the caller's block (no staging copy of 32 B x grid points per mode)
+    std::vector<double> d(det_out ? 0 : n);
+    const int rc = Ops::eigenvector_batch(solvers[0], freq, n, det_out ? det_out : d.data(), vec_out);
+    if (rc != STORM_OK) fail(rc, "device 0: " + Ops::last_error());
+    return;
+  }
   on_every_device(D, [&](size_t k) {
-    std::vector<double> f, d, v;
+    std::vector<double> f, d;
     for (size_t j = k; j < n; j += D) f.push_back(freq[j]);
     if (f.empty()) return int(STORM_OK);
-    d.resize(f.size()); v.resize(f.size() * len);
-    const int rc = Ops::eigenvector_batch(solvers[k], f.data(), f.size(), d.data(), v.data());
+    d.resize(f.size());
+    std::unique_ptr<double[]> v(new double[f.size() * len]);  // (uninitialised: every element is written by the call)
+    const int rc = Ops::eigenvector_batch(solvers[k], f.data(), f.size(), d.data(), v.get());
     if (rc != STORM_OK) return rc;
     for (size_t i = 0, j = k; j < n; j += D, ++i) {
-      std::memcpy(vec_out + j * len, v.data() + i * len, len * sizeof(double));
+      std::memcpy(vec_out + j * len, v.get() + i * len, len * sizeof(double));
       if (det_out) det_out[j] = d[i];
     }
     return int(STORM_OK);

@@ -499,7 +499,11 @@ size_t hex_whole_rounds(storm_solver* s, size_t n, SegPlan& rest) {
   const size_t per_round = info[0];
   // (a remainder above a quarter round is cheaper inside det_hex: measured 20 000 frequencies 5.07 ms whole, 5.38 ms split)
   if (info[1] || !per_round || n <= per_round || n % per_round == 0 || n % per_round > per_round / 4) return n;
-  rest = plan_segments(s, n % per_round, n_int, 31);
+  // enough segments for the remainder's (frequency, segment) groups to fill ~85 % of the chip's 16-lane group slots (=
+  // per_round): its launch then takes the time of one segment's chain, and the more segments the shorter that is (213
+  // frequencies: 31 segments of 336 intervals 85 us, 51 of 208 ~50 us)
+  const size_t rest_n = n % per_round;
+  rest = plan_segments(s, rest_n, n_int, std::min<size_t>(255, std::max<size_t>(31, per_round * 85 / 100 / rest_n)));
   return rest.n_seg ? n - n % per_round : n;
 }
 
@@ -1180,32 +1184,41 @@ static void scan_on_device(storm_solver* s, const double* freq, size_t n, bool r
   hip_check(hipMemcpyAsync(s->d_freq.p, freq, n * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
   det_device(s, s->d_freq.p, n, s->d_det.p, st);
   if (det_out) hip_check(hipMemcpyAsync(det_out, s->d_det.p, n * sizeof(double), hipMemcpyDeviceToHost, st), "det D2H");
+  // sign-swap filter, compaction and (if asked) refinement as ONE stream of launches: count per block -> exclusive sum on
+  // the device -> emit in ascending order -> the total and the flags come to the host with one synchronisation (round 2:
+  // counts to the host, sum there, offsets back, a second synchronisation after the emission)
   const size_t nb = swap_blocks(n);
+  const size_t room = std::min(cap, n - 1 ? n - 1 : 1);   // brackets the device may write: the caller's, at most one per pair
   s->d_bcount.reserve(nb + 4, st);
   s->d_bflags.reserve(2, st);
+  s->d_br.reserve(std::max<size_t>(room, 1), st); s->d_bidx.reserve(std::max<size_t>(room, 1), st);
   hip_check(hipMemsetAsync(s->d_bflags.p, 0, 2 * sizeof(int), st), "flags memset");
   hip_check(storm::launch_swap_count(s->d_det.p, n, s->d_bcount.p, s->d_bflags.p, st), "swap_count launch");
-  BracketStage stage = bracket_stage(s, nb, 0);
-  if (nb) hip_check(hipMemcpyAsync(stage.counts, s->d_bcount.p, nb * sizeof(unsigned), hipMemcpyDeviceToHost, st), "counts D2H");
+  hip_check(storm::launch_swap_offsets(s->d_bcount.p, nb, st), "swap_offsets launch");
+  hip_check(storm::launch_swap_emit(s->d_freq.p, s->d_det.p, n, s->d_bcount.p, room, s->d_br.p, s->d_bidx.p, st), "swap_emit launch");
+  count_launch(s, 3);
+  // a scan finds a few dozen brackets: without refinement the first kEarly of them ride along with the total
+  constexpr size_t kEarly = 256;
+  BracketStage stage = bracket_stage(s, nb, kEarly);
+  hip_check(hipMemcpyAsync(stage.counts, s->d_bcount.p + nb, sizeof(unsigned), hipMemcpyDeviceToHost, st), "total D2H");
   hip_check(hipMemcpyAsync(stage.flags, s->d_bflags.p, sizeof(int), hipMemcpyDeviceToHost, st), "flags D2H");
+  const size_t early = refine ? 0 : std::min(room, kEarly);
+  if (early) {
+    hip_check(hipMemcpyAsync(stage.br, s->d_br.p, early * sizeof(BracketDev), hipMemcpyDeviceToHost, st), "brackets D2H");
+    hip_check(hipMemcpyAsync(stage.idx, s->d_bidx.p, early * sizeof(unsigned long long), hipMemcpyDeviceToHost, st), "index D2H");
+  }
   check_flags(s);  // synchronises; singular stage matrices
-  count_launch(s);
-  size_t total = 0;
-  for (size_t b = 0; b < nb; ++b) { const unsigned c = stage.counts[b]; stage.counts[b] = unsigned(total); total += c; }
+  const size_t total = stage.counts[0];
   if (had_invalid) *had_invalid = (*stage.flags & 2) ? 1 : 0;
   *n_out = total;
   if (total > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
   if (total == 0) return;
   if (total > (size_t(1) << 31)) fail(STORM_ERR_CAPACITY, "too many brackets");
-  s->d_br.reserve(total, st); s->d_bidx.reserve(total, st);
-  hip_check(hipMemcpyAsync(s->d_bcount.p, stage.counts, nb * sizeof(unsigned), hipMemcpyHostToDevice, st), "offsets H2D");
-  hip_check(storm::launch_swap_emit(s->d_freq.p, s->d_det.p, n, s->d_bcount.p, s->d_br.p, s->d_bidx.p, st), "swap_emit launch");
-  count_launch(s);
-  stage = bracket_stage(s, nb, total);  // (may move the pinned block: the offsets upload must have been consumed)
-  if (refine) {
-    refine_device(s, total, ulp, stage);
+  if (refine || total > early) {
+    stage = bracket_stage(s, nb, total);  // (may move the pinned block: nothing in it is needed any more)
+    if (refine) refine_device(s, total, ulp, stage);
+    download_brackets(s, total, stage, true);
   }
-  download_brackets(s, total, stage, true);
   for (size_t k = 0; k < total; ++k) {
     const BracketDev& b = stage.br[k];
     if (!std::isfinite(b.lo_x) || !std::isfinite(b.hi_x)) fail(STORM_ERR_BRACKET, "non-finite scan frequency");

@@ -175,7 +175,9 @@ static void cache_stress(unsigned seed, int n_threads, int iters) {
 }
 
 // ------------------------------------------------------------------------------------------------ brackets
-static double toy_det(double x, double shift) { return std::sin(3.14159265358979323846 * (x - shift)) * std::exp(x / 7.0); }
+static double toy_det(double x, double shift, double wiggle = 1.0) {
+  return std::sin(3.14159265358979323846 * wiggle * (x - shift)) * std::exp(x / 7.0);
+}
 
 static void brackets_unit() {
   const size_t n = 400;
@@ -227,7 +229,7 @@ static void brackets_unit() {
 }
 
 // ------------------------------------------------------------------------------------------------ multi
-struct ToySolver { double shift; size_t n_int; int fail_in = 0; /* 1: scan, 2: optimize, 3: eigenvectors */ };
+struct ToySolver { double shift; size_t n_int; int fail_in = 0; /* 1: scan, 2: optimize, 3: eigenvectors */ double wiggle = 1.0; };
 static thread_local std::string toy_error;
 struct ToyOps {
   using Solver = ToySolver*;
@@ -235,7 +237,7 @@ struct ToyOps {
                            double* det_out, uint64_t* index_out) {
     if (s->fail_in == 1) { toy_error = "toy scan failure"; return STORM_ERR_HIP; }
     std::vector<double> d(n);
-    for (size_t i = 0; i < n; ++i) d[i] = toy_det(freq[i], s->shift);
+    for (size_t i = 0; i < n; ++i) d[i] = toy_det(freq[i], s->shift, s->wiggle);
     if (det_out) std::copy(d.begin(), d.end(), det_out);
     std::vector<BracketState> br;
     std::vector<uint64_t> idx;
@@ -255,7 +257,7 @@ struct ToyOps {
     std::vector<BracketState> br(n);
     for (size_t k = 0; k < n; ++k) { br[k].lower = Pt{b[k].lo_x, b[k].lo_f}; br[k].upper = Pt{b[k].hi_x, b[k].hi_f}; }
     try {
-      refine_brackets(br, ulp, [&](const double* xs, size_t m, double* fs) { for (size_t k = 0; k < m; ++k) fs[k] = toy_det(xs[k], s->shift); });
+      refine_brackets(br, ulp, [&](const double* xs, size_t m, double* fs) { for (size_t k = 0; k < m; ++k) fs[k] = toy_det(xs[k], s->shift, s->wiggle); });
     } catch (const Failure& f) { toy_error = f.msg; return f.code; }
     for (size_t k = 0; k < n; ++k)
       b[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f, br[k].root, br[k].evals};
@@ -265,7 +267,7 @@ struct ToyOps {
     if (s->fail_in == 3) { toy_error = "toy eigenvector failure"; return STORM_ERR_SINGULAR; }
     const size_t len = (s->n_int + 1) * 4;
     for (size_t k = 0; k < n; ++k) {
-      det_out[k] = toy_det(freq[k], s->shift);
+      det_out[k] = toy_det(freq[k], s->shift, s->wiggle);
       for (size_t i = 0; i < len; ++i) vec_out[k * len + i] = freq[k] * double(i + 1);
     }
     return STORM_OK;
@@ -276,10 +278,11 @@ struct ToyOps {
 
 static bool same_bits(double a, double b) { return bits_of(a) == bits_of(b); }
 
-static void multi_unit(size_t n, size_t D, uint64_t ulp) {
+static void multi_unit(size_t n, size_t D, uint64_t ulp, double wiggle = 1.0) {
   std::vector<double> f(n);
   for (size_t i = 0; i < n; ++i) f[i] = 0.25 + 30.0 * double(i) / double(n > 1 ? n - 1 : 1);
   ToySolver one{0.125, 37};
+  one.wiggle = wiggle;
   std::vector<ToySolver> devs(D, one);
   std::vector<ToySolver*> ptr1{&one}, ptrD;
   for (auto& d : devs) ptrD.push_back(&d);
@@ -361,6 +364,7 @@ int main(int argc, char** argv) {
   std::printf("  brackets: ok\n");
   for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(5), size_t(333), size_t(2000)})
     for (size_t D : {size_t(1), size_t(2), size_t(3), size_t(5), size_t(8)}) multi_unit(n, D, n % 2 ? 1 : 45035996);
+  multi_unit(60000, 2, 45035996, 700.0);   // ~21 000 brackets: a slice holds more than the first call's room for 8192
   multi_errors();
   {  // several multi-device scans at once (the library allows one handle per host thread)
     std::vector<std::thread> pool;

@@ -38,7 +38,9 @@ def dispatches(d, counters):
     """[(dispatch id, kernel name, grid, {counter: value}, duration us)] in launch order"""
     rows = {}
     pat = "*counter_collection.csv" if counters else "*kernel_trace.csv"
-    for f in glob.glob(os.path.join(d, "**", pat), recursive=True):
+    # (one process per pass; if the directory holds the files of several runs -- gpurun merges into what is there -- the newest)
+    files = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             k = int(r["Dispatch_Id"])
             e = rows.setdefault(k, [k, r["Kernel_Name"], 0, {}, 0.0, 0, 0])
