@@ -312,23 +312,35 @@ def main():
         h.kernel_times(reset=True)
         sync()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(steps):
             res = one_scan()
+            marks.append(time.perf_counter())  # (a scan ends synchronised: its results are on the host)
         sync()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        step_ms = [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)]
         st = h.stats()
         det_evals, refine, eigs, rounds, launches = sum_over_ranks(
             [st["det_evals"], st["refine_evals"], st["eigenvectors"], st["refine_rounds"], st["launches"]])
         kt = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_ms": round(v[0] / v[1], 4)}
               for k, v in h.kernel_times(reset=True).items() if v[1]}
         return {"elapsed": elapsed, "modes": len(res), "det_evals": det_evals, "refine": refine, "eigs": eigs,
-                "rounds_per_scan": rounds / steps / world, "launches_per_scan": launches / steps / world, "kernels": kt}
+                "rounds_per_scan": rounds / steps / world, "launches_per_scan": launches / steps / world, "kernels": kt,
+                "step_ms": step_ms}
 
+    # The interpreter's full garbage collection walks every object `import torch` left behind (~40 ms) and its turn comes
+    # after a number of allocations, i.e. inside some step or other (seen as one 52 ms step among 16 ms ones under `step_ms`,
+    # in the first process of a fresh tree, whose byte-compilation shifts the count).  Collect now and move what exists to the
+    # permanent generation: the collector stays on, its later passes see the benchmark's own few objects only.
+    import gc
+    gc.collect()
+    gc.freeze()
+    # Order: the two kernel-alone timings and the other build's leg first, the headline region last.
     main_arith = 1 if args.arithmetic == "fast" else 0
-    res = measure(main_arith, args.steps, args.warmup)
     other_steps = max(1, min(args.steps, 5))
+    roof = {a: (roofline_of(a) if rank == 0 else None) for a in (0, 1)}  # (HIP-event timed: a host stall does not show)
     other = measure(1 - main_arith, other_steps, 1)
-    roof = {a: (roofline_of(a) if rank == 0 else None) for a in (0, 1)}
+    res = measure(main_arith, args.steps, args.warmup)
 
     def phase_times(steps=5):
         """Where a step goes, per rank: the scan of the rank's slice, the gather of the unrefined brackets, the refinement of
@@ -431,13 +443,15 @@ def main():
             "modes_per_s": res["eigs"] / res["elapsed"], "modes_per_step": res["modes"],
             "det_evals": res["det_evals"], "refine_evals": res["refine"],
             "refine_rounds_per_scan": res["rounds_per_scan"], "launches_per_scan": res["launches_per_scan"],
-            "fast_vs_parity": identity, "kernels": res["kernels"], "roofline": roof[main_arith],
+            "fast_vs_parity": identity, "kernels": res["kernels"], "step_ms": res["step_ms"],
+            "ms_per_step_median": sorted(res["step_ms"])[len(res["step_ms"]) // 2],
+            "roofline": roof[main_arith],
             "phases": phases, "multi_in_library": multi,
             f"{name_other}_arithmetic": {
                 "value": other["det_evals"] * n_int / other["elapsed"], "unit": "freq*interval evals/s",
                 "steps": other_steps, "ms_per_step": other["elapsed"] / other_steps * 1e3,
                 "modes_per_s": other["eigs"] / other["elapsed"], "modes_per_step": other["modes"],
-                "kernels": other["kernels"], "roofline": roof[1 - main_arith]},
+                "kernels": other["kernels"], "step_ms": other["step_ms"], "roofline": roof[1 - main_arith]},
             "eigenvector_roofline": eigen_roofline(),
         }
     if rank == 0 and world == 1 and args.legs == "all":
