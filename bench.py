@@ -63,6 +63,30 @@ def executed_entry(group, arithmetic, **match):
     return cand[0]
 
 
+def pipe_breakdown(e, launch_ms):
+    """Where 1 - frac goes, from the same counters: the FP64 pipe's busy share at the clock the profile saw, that clock against
+    the 2.4 GHz the peak assumes, and the share of pipe slots that hold one flop (mul, add, rcp) instead of two (fma, mfma).
+    Cycles per wave instruction on a SIMD: v_fma/mul/add_f64 4, v_rcp_f64 and friends 16, v_mfma_f64_4x4x4 16,
+    v_mfma_f64_16x16x4 64 (tools/fp64_microbench.hip, tools/mfma64_microbench.hip)."""
+    k = e["kernels"][e["dominant_kernel"]]
+    c = k["counters_per_call"]
+    g = lambda n: float(c.get(n, 0.0))
+    mfma_cycles, mfma_flops = (64, 2048) if "coupling_matrix" in e["dominant_kernel"] else (16, 512)
+    fma, mul, add, trans, mfma = (g("SQ_INSTS_VALU_FMA_F64"), g("SQ_INSTS_VALU_MUL_F64"), g("SQ_INSTS_VALU_ADD_F64"),
+                                  g("SQ_INSTS_VALU_TRANS_F64"), g("SQ_INSTS_VALU_MFMA_F64"))
+    busy = 4 * (fma + mul + add) + 16 * trans + mfma_cycles * mfma
+    flops = 128 * fma + 64 * (mul + add + trans) + mfma_flops * mfma
+    if not busy or not g("SQ_BUSY_CYCLES"):
+        return None
+    clock_ghz = g("SQ_BUSY_CYCLES") / 32 / k["us_per_call"] / 1e3      # (SQ_BUSY_CYCLES sums over 8 XCDs x 4 shader engines)
+    simd_cycles = launch_ms * 1e-3 * clock_ghz * 1e9 * 1024
+    return {"fp64_pipe_busy": round(busy / simd_cycles, 3), "clock_ghz_in_profile": round(clock_ghz, 3),
+            "clock_over_peak_clock": round(clock_ghz / 2.4, 3), "flops_per_pipe_cycle_over_32": round(flops / busy / 32, 3),
+            "product": round(busy / simd_cycles * clock_ghz / 2.4 * flops / busy / 32, 3),
+            "what": "frac ~= fp64_pipe_busy x clock_over_peak_clock x flops_per_pipe_cycle_over_32 (pipe cycles from the "
+                    "instruction counters, the clock from SQ_BUSY_CYCLES of the profiled launch, live launch time)"}
+
+
 def executed_source(e):
     return {"file": "profiles/r03_executed_flops.json", "commit": EXECUTED.get("commit"), "group": e["group"],
             "kernel": e["dominant_kernel"], "units_per_call": e["units_per_call"],
@@ -291,7 +315,7 @@ def main():
                              "algorithmic bytes: coefficient planes once (2.7 MB) + 16 B per frequency",
              "avg_launch_ms": round(ms / cnt, 4), "launches_timed": cnt, "flops_per_launch": flops_per_launch,
              "executed_flops_per_eval": round(ex["executed_flops_per_unit"], 2), "executed_from": executed_source(ex),
-             "profiled_batch_matches": ex["n_freq"] == len(mine),
+             "profiled_batch_matches": ex["n_freq"] == len(mine), "breakdown": pipe_breakdown(ex, ms / cnt),
              "reference_equivalent": {"flops_per_eval": FLOPS_PER_EVAL["colloc4"], "achieved": round(ref_eq, 3), "unit": "TFLOP/s",
                                       "ratio_to_peak": round(ref_eq / PEAK_FP64_TFLOPS, 4),
                                       "what": "the reference formulation's un-fused flops for the same evaluations / time"},
@@ -369,7 +393,14 @@ def main():
                 "max_over_ranks": {k: round(v, 4) for k, v in zip(names, worst)},
                 "sum_of_max": round(sum(worst), 4)}
 
-    phases = phase_times()
+    def leg(fn, *a):
+        """A leg that is not `value`: an exception in it is reported in its place instead of costing the whole line."""
+        try:
+            return fn(*a)
+        except Exception as e:  # noqa: BLE001 (reported, not hidden: the key then holds the error text)
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    phases = phase_times() if world > 1 else leg(phase_times)  # (N > 1: every rank is inside its collectives, no lone catch)
 
     def multi_in_library(steps=5):
         """The same strong-scaled scan through storm_multi_* (include/storm_hip.h): ONE process, one solver and one host
@@ -399,9 +430,12 @@ def main():
                 "value": st["det_evals"] * n_int / dt, "unit": "freq*interval evals/s",
                 "bracket_indices_equal_headline": indices_of(res) == idx_f}
 
-    multi = multi_in_library() if rank == 0 else None
+    # While rank 0 drives all N devices the other ranks wait on the HOST (a gloo group): a barrier of the GPU backend would
+    # keep a spinning kernel on every device the leg is about to time.
+    host_group = dist.new_group(backend="gloo") if world > 1 and args.dist_backend == "nccl" else None
+    multi = leg(multi_in_library) if rank == 0 else None
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=host_group)
     h.set_option("arithmetic", 0)
 
     def eigen_roofline():

@@ -364,3 +364,15 @@ def test_strong_scaling_with_hip_on_every_rank(tmp_path, oracle, oracle_models):
         share = D.deal(len(ref), world, r)
         assert np.load(tmp_path / f"idx{r}.npy").tolist() == [ref[k]["index"] for k in share]
         assert same_bits(np.load(tmp_path / f"vec{r}.npy"), rvec[share])
+
+
+def test_exchange_path_over_rccl_one_rank():
+    """The N > 1 exchange (storm_amd/distributed.py: pinned mirrors, device tensors, all_gather_into_tensor) with RCCL as
+    the backend.  One rank is all a one-GPU box can give RCCL (it refuses two ranks on one device); the communicator, the
+    collective form and the buffers are the ones N ranks use.  Own process: the test session must not own a process group."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(36000 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_one_rank.py")], env=env, capture_output=True,
+                       text=True, timeout=150)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok " in r.stdout and "gather_brackets over RCCL" in r.stdout

@@ -7,7 +7,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <int ILP, int MODE>  // MODE 0: fma, 1: mul then add (un-fused), 2: add only
+template <int ILP, int MODE>  // MODE 0: fma, 1: mul then add (un-fused), 2: add only, 3: v_rcp_f64
 __global__ void valu_kernel(double* out, int iters, double a, double b) {
   double x[ILP];
 #pragma unroll
@@ -19,6 +19,7 @@ __global__ void valu_kernel(double* out, int iters, double a, double b) {
       for (int i = 0; i < ILP; ++i) {
         if (MODE == 0) x[i] = __builtin_fma(x[i], a, b);
         else if (MODE == 1) { double t = x[i] * a; asm volatile("" : "+v"(t)); x[i] = t + b; }
+        else if (MODE == 3) x[i] = __builtin_amdgcn_rcp(x[i]);
         else x[i] = x[i] + b;
       }
     }
@@ -95,6 +96,8 @@ int main() {
     printf("1 wave  fma  ILP8 : %.2f ns/op\n", ms * 1e6 / (iters * 64.0));
     ms = time_ms([&] { valu_kernel<8, 2><<<1, 64>>>(d, iters, 1.0000001, 1e-9); });
     printf("1 wave  add  ILP8 : %.2f ns/op\n", ms * 1e6 / (iters * 64.0));
+    ms = time_ms([&] { valu_kernel<8, 3><<<1, 64>>>(d, iters, 1.0000001, 1e-9); });
+    printf("1 wave  rcp  ILP8 : %.2f ns/op (v_rcp_f64; against fma ILP8: cycles per wave instruction = 4 x the ratio)\n", ms * 1e6 / (iters * 64.0));
     ms = time_ms([&] { dpp_chain_kernel<<<1, 64>>>(d, iters, 1e-9); });
     printf("1 wave  dpp+add chain : %.2f ns/step\n", ms * 1e6 / (iters * 8.0));
     ms = time_ms([&] { shfl_chain_kernel<<<1, 64>>>(d, iters, 1e-9); });
@@ -110,6 +113,8 @@ int main() {
     printf("%d waves/SIMD fma    : %.1f TFLOP/s (fma = 2 flop)\n", wps, 2 * ops / (ms * 1e-3) / 1e12);
     ms = time_ms([&] { valu_kernel<8, 1><<<blocks, 256>>>(d, iters, 1.0000001, 1e-9); });
     printf("%d waves/SIMD mul+add: %.1f TFLOP/s (2 instr = 2 flop)\n", wps, 2 * ops / (ms * 1e-3) / 1e12);
+    ms = time_ms([&] { valu_kernel<8, 3><<<blocks, 256>>>(d, iters, 1.0000001, 1e-9); });
+    printf("%d waves/SIMD rcp    : %.2f T v_rcp_f64 lanes/s\n", wps, ops / (ms * 1e-3) / 1e12);
   }
   hipFree(d);
   return 0;
