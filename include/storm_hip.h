@@ -181,13 +181,15 @@ int storm_postproc_create(const storm_model_desc* model, storm_postproc** out);
 void storm_postproc_destroy(storm_postproc* post);
 /* Options of a post-processing handle (no counterpart in the reference).  "arithmetic": 0 (default) = the coupling
  * integrals of storm_coupling_matrices / storm_sweep_coupling_matrices keep the reference's association and are
- * bit-identical to its sequential sums (src/perturbed.rs:148-261); 1 = the FMA build (the same integrands re-associated,
- * about twice as fast; 16 x 16 tiles whose left modes share one degree and whose right modes share one are summed on
- * v_mfma_f64_16x16x4, four grid points per instruction): every matrix element within 1e-12 of the largest magnitude of
- * its matrix (tests/test_hip_coupling.py; measured 1e-14).  "coupling_tile": 0 (default, automatic), 8 or 16 modes per
- * side of a workgroup's tile of pairs; never changes a bit of the result in the parity build (in the FMA build only
- * tiles of 16 take the matrix instructions).  The fields, norms and mode identification of storm_postprocess_batch are
- * always computed in the reference's arithmetic.
+ * bit-identical to its sequential sums (src/perturbed.rs:148-261); 1 = the FMA build (the same integrands re-associated
+ * and summed on v_mfma_f64_16x16x4, four grid points per instruction, over the modes ordered by degree inside the library:
+ * the caller's order is free): every matrix element within 1e-12 of the largest magnitude of its matrix
+ * (tests/test_hip_coupling.py; measured 1e-14), the same bits on every run.  Speed only, never the contract:
+ * "coupling_tile": 0 (default, automatic), 8 or 16 modes per side of a workgroup's tile of pairs in the vector walk (the
+ * parity build's kernel: never changes a bit there); FMA build: "coupling_matrix" 1 (default) = the matrix-pipe walk, 0 =
+ * the vector walk; "coupling_matrix_tile" 0 (automatic), 16 or 32; "coupling_split" 0 (automatic) or 1..64 = pieces the grid
+ * is cut into per tile (their sums are added in ascending order by a second launch; 1 = no split).  The fields, norms and
+ * mode identification of storm_postprocess_batch are always computed in the reference's arithmetic.
  * storm_sweep_coupling_matrices_batch follows the sweep's own "arithmetic" option. */
 int storm_postproc_set_option(storm_postproc* post, const char* key, int64_t value);
 

@@ -5,6 +5,7 @@
 #include "postprocess.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <type_traits>
 #include "shared_div.hpp"
@@ -107,7 +108,7 @@ constexpr int kCpRing = 3;  // chunks staged at once in the matrix-pipe walk (kC
 constexpr int kCpGroup = 4 * kCpChunk + 2;
 PDEV int cp_slot(int mode) { return (mode >> 2) * kCpGroup + (mode & 3) * kCpChunk; }
 
-PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
+PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r, unsigned piece) {
   constexpr int kCpTile = 16, kCpPlane = 4 * kCpGroup, kCpFields = 9 * kCpPlane, kCpBufs = kCpRing;
   constexpr int kCpTileDoubles = kCpFields + kCpChunk * kCouplingWeights;  // fields, then the points' weights
   __shared__ __attribute__((aligned(16))) double tiles[kCpBufs][kCpTileDoubles];
@@ -173,7 +174,10 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     // waiting for its data.  Every chunk is requested -- past the grid's end as clamped copies of the last point, which
     // `valid` keeps out of the sums -- so the count of requests in flight is the same constant at every wait.
     constexpr int kAhead = kCpBufs - 1;
-    const size_t n_chunks = (np - 1 + kCpChunk - 1) / kCpChunk;
+    const size_t n_chunks_all = (np - 1 + kCpChunk - 1) / kCpChunk;
+    // this workgroup's piece of the grid (CouplingArgs::n_split; requests past its end fetch the next piece's points or
+    // clamped copies: never used)
+    const size_t chunk0 = n_chunks_all * piece / a.n_split, n_chunks = n_chunks_all * (piece + 1) / a.n_split;
     // Field staging of this walk: LDS image [plane][mode][point], one DMA instruction = 4 modes x 8 points, 16
     // consecutive lanes on the 64 consecutive bytes of one mode's chunk (the vector walk's image is [point][mode]: 2
     // points x 16 modes per instruction, i.e. 16 cache lines touched for 256 bytes -- at this walk's pace the address
@@ -199,8 +203,8 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
       stage_fields(1 + chunk * kCpChunk, tile);
       stage_weights(1 + chunk * kCpChunk, tile);
     };
-    for (int k = 0; k < kAhead; ++k) request(k);
-    for (size_t chunk = 0; chunk < n_chunks; ++chunk) {
+    for (int k = 0; k < kAhead; ++k) request(chunk0 + k);
+    for (size_t chunk = chunk0; chunk < n_chunks; ++chunk) {
       const size_t rc0 = 1 + chunk * kCpChunk;
       // requests of the kAhead - 1 later chunks may stay in flight: 9 field + 1 weight instructions each, wave 0 one more
       // (the null walk: 4 field instructions)
@@ -305,6 +309,7 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     __syncthreads();
     if (grp == 0) {
       const size_t mm2 = M * M;
+      double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * kCouplingMatrices * mm2 : a.out;
       const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
       const double F = a.freq[rj >= 0 ? rj : 0];
       bool ok = true;
@@ -316,19 +321,19 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
         if (null_walk) {
           if (half == 0) {
             const double lz = lz0[v * 64 + lane] + acc[2][v];
-            a.out[0 * mm2 + at] = 0.0; a.out[1 * mm2 + at] = 0.0; a.out[2 * mm2 + at] = 0.0;
-            a.out[5 * mm2 + at] = lz;
+            out[0 * mm2 + at] = 0.0; out[1 * mm2 + at] = 0.0; out[2 * mm2 + at] = 0.0;
+            out[5 * mm2 + at] = lz;
             ok = ok && isfinite(lz);
           } else {
-            a.out[3 * mm2 + at] = 0.0; a.out[4 * mm2 + at] = 0.0;
+            out[3 * mm2 + at] = 0.0; out[4 * mm2 + at] = 0.0;
           }
         } else if (half == 0) {
           const double lz = lz0[v * 64 + lane] + F * (acc[3][v] + F * acc[4][v]);
-          a.out[0 * mm2 + at] = acc[0][v]; a.out[1 * mm2 + at] = acc[1][v]; a.out[2 * mm2 + at] = acc[2][v];
-          a.out[5 * mm2 + at] = lz;
+          out[0 * mm2 + at] = acc[0][v]; out[1 * mm2 + at] = acc[1][v]; out[2 * mm2 + at] = acc[2][v];
+          out[5 * mm2 + at] = lz;
           ok = ok && isfinite(acc[0][v]) && isfinite(lz);
         } else {
-          a.out[3 * mm2 + at] = acc[0][v]; a.out[4 * mm2 + at] = acc[1][v];
+          out[3 * mm2 + at] = acc[0][v]; out[4 * mm2 + at] = acc[1][v];
           ok = ok && isfinite(acc[0][v]);
         }
       }
@@ -352,7 +357,7 @@ constexpr int kCp32TileDoubles = kCp32Fields + kCpChunk * kCouplingWeights + 32;
 constexpr int kCp32Ring = 3;   // (a ring of 2 with four workgroups per CU was measured: 8.7 vs 8.2 ms at M = 1024 -- the compiler
 // does not reach four waves per SIMD at 116 registers, and with two a chunk of lookahead is not enough)
 
-PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r) {
+PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigned tile_r, unsigned piece) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) double tiles[kCp32Ring][kCp32TileDoubles];
   const int lane = threadIdx.x & 63;
@@ -398,14 +403,15 @@ PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigne
     rbase[j] = reinterpret_cast<const char*>(a.fields + rrow * kPostFields * np) + (lane & 15) * 4;
   }
   const char* wbase = reinterpret_cast<const char*>(a.weights) + lane * 4;
-  const size_t n_chunks = (np - 1 + kCpChunk - 1) / kCpChunk;
+  const size_t n_chunks_all = (np - 1 + kCpChunk - 1) / kCpChunk;
+  const size_t chunk0 = n_chunks_all * piece / a.n_split, n_chunks = n_chunks_all * (piece + 1) / a.n_split;  // this piece
   constexpr int kAhead = kCp32Ring - 1;
   auto request = [&](size_t chunk) {
     // past the grid's end the last chunk is requested again (its data is never used): the count of requests in flight
     // stays the same constant at every wait.  The last chunk itself may reach up to 7 points past the grid: those bytes
     // belong to the next plane of the same mode (none of the staged planes is a mode's last) or to the 16 spare rows of
     // the weights, and `valid` keeps them out of the sums.
-    const size_t ch = chunk < n_chunks ? chunk : n_chunks - 1;
+    const size_t ch = chunk < n_chunks_all ? chunk : n_chunks_all - 1;
     const size_t byte0 = (1 + ch * kCpChunk) * sizeof(double);   // wave-uniform
     double* tile = tiles[chunk % kCp32Ring];
     constexpr int kPlanes[9] = {XI_R, XI_H, PSI, PRS, XI_R, XI_H, XI_TP, XI_TN, RHO};  // 4 left, 5 right
@@ -431,8 +437,8 @@ PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigne
 #pragma unroll
   for (int o = 0; o < 8; ++o) acc[o] = v4d{0.0, 0.0, 0.0, 0.0};
   const int mi = lane & 15, kpt = lane >> 4;
-  for (int k = 0; k < kAhead; ++k) request(k);
-  for (size_t chunk = 0; chunk < n_chunks; ++chunk) {
+  for (int k = 0; k < kAhead; ++k) request(chunk0 + k);
+  for (size_t chunk = chunk0; chunk < n_chunks; ++chunk) {
     const size_t rc0 = 1 + chunk * kCpChunk;
     if (null_stage) {
       if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * 10) : "memory");
@@ -511,6 +517,7 @@ PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigne
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the grid's end land in this workgroup's LDS
   if (!exists) return;
   const size_t mm2 = M * M;
+  double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * kCouplingMatrices * mm2 : a.out;
   const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
   const double F = a.freq[rj >= 0 ? rj : 0];
   bool ok = true;
@@ -520,15 +527,15 @@ PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigne
     if (rj < 0 || li < 0) continue;
     const size_t at = size_t(li) + size_t(rj) * M;
     if (null_walk) {
-      a.out[0 * mm2 + at] = 0.0; a.out[1 * mm2 + at] = 0.0; a.out[2 * mm2 + at] = 0.0;
-      a.out[3 * mm2 + at] = 0.0; a.out[4 * mm2 + at] = 0.0;
-      a.out[5 * mm2 + at] = acc[7][v];
+      out[0 * mm2 + at] = 0.0; out[1 * mm2 + at] = 0.0; out[2 * mm2 + at] = 0.0;
+      out[3 * mm2 + at] = 0.0; out[4 * mm2 + at] = 0.0;
+      out[5 * mm2 + at] = acc[7][v];
       ok = ok && isfinite(acc[7][v]);
     } else {
       const double lz = acc[7][v] + F * (acc[3][v] + F * acc[4][v]);
-      a.out[0 * mm2 + at] = acc[0][v]; a.out[1 * mm2 + at] = acc[1][v]; a.out[2 * mm2 + at] = acc[2][v];
-      a.out[3 * mm2 + at] = acc[5][v]; a.out[4 * mm2 + at] = acc[6][v];
-      a.out[5 * mm2 + at] = lz;
+      out[0 * mm2 + at] = acc[0][v]; out[1 * mm2 + at] = acc[1][v]; out[2 * mm2 + at] = acc[2][v];
+      out[3 * mm2 + at] = acc[5][v]; out[4 * mm2 + at] = acc[6][v];
+      out[5 * mm2 + at] = lz;
       ok = ok && isfinite(acc[0][v]) && isfinite(acc[5][v]) && isfinite(lz);
     }
   }
@@ -863,15 +870,31 @@ inline unsigned cp_grid_single(unsigned T) {  // workgroups of a one-problem lau
 }
 inline unsigned cp_per_problem(unsigned T) { return T * T; }  // workgroups per problem of a batch launch (a problem stays on one XCD)
 template <int TILE>
-PDEV void coupling_matrix_dispatch(const CouplingArgs& a, unsigned tl, unsigned tr) {
-  if constexpr (TILE == 16) coupling_matrix_body(a, tl, tr);
-  else coupling_matrix32_body(a, tl, tr);
+PDEV void coupling_matrix_dispatch(const CouplingArgs& a, unsigned tl, unsigned tr, unsigned piece) {
+  if constexpr (TILE == 16) coupling_matrix_body(a, tl, tr, piece);
+  else coupling_matrix32_body(a, tl, tr, piece);
 }
+// One problem: `per` = cp_grid_single(T) workgroups per piece of the grid, the pieces one after the other in launch order
+// (per is a multiple of 8: a tile's pieces stay on the tile's XCD).
 template <int TILE>
-__global__ __launch_bounds__(256, 2) void coupling_matrix_kernel(CouplingArgs a) {
+__global__ __launch_bounds__(256, 2) void coupling_matrix_kernel(CouplingArgs a, unsigned per) {
+  const unsigned piece = blockIdx.x / per, b = blockIdx.x % per;
   unsigned tl, tr;
-  if (!cp_tile_of(blockIdx.x % kCpXcds, blockIdx.x / kCpXcds, kCpXcds, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
-  coupling_matrix_dispatch<TILE>(a, tl, tr);
+  if (!cp_tile_of(b % kCpXcds, b / kCpXcds, kCpXcds, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
+  coupling_matrix_dispatch<TILE>(a, tl, tr, piece);
+}
+// out[i] = partial[0][i] + partial[1][i] + ... (ascending: the same sum on every run), i < n; a non-finite sum raises the flag.
+__global__ __launch_bounds__(256) void coupling_pieces_kernel(const double* __restrict__ partial, unsigned n_split, size_t n,
+                                                              double* __restrict__ out, int* flags) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  bool ok = true;
+  if (i < n) {
+    double s = partial[i];
+    for (unsigned k = 1; k < n_split; ++k) s += partial[size_t(k) * n + i];
+    out[i] = s;
+    ok = isfinite(s);
+  }
+  if (__syncthreads_or(!ok) && threadIdx.x == 0) atomicOr(flags, 1);
 }
 // several problems: problem p runs on XCD p % 8 (its modes are read by no other problem), per_problem workgroups each
 template <int TILE>
@@ -883,7 +906,7 @@ __global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const Cou
   const CouplingArgs a = table[p];
   unsigned tl, tr;
   if (!cp_tile_of(0, k % per_problem, 1, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
-  coupling_matrix_dispatch<TILE>(a, tl, tr);
+  coupling_matrix_dispatch<TILE>(a, tl, tr, 0);
 }
 // 32 x 32 tiles from this many workgroups on (one per CU and a few more): below, the 16 x 16 walk's four times as many
 // smaller workgroups fill the chip better.  0 < `force` = 16 or 32 overrides (option "coupling_matrix_tile").
@@ -894,6 +917,39 @@ inline bool cp_use_tiles32(size_t tiles32_total, int force) {
 }
 #endif
 }  // namespace
+
+#ifdef STORM_FAST_BUILD
+// Workgroups of the matrix-pipe walks that the chip holds at once: 32 x 32 tiles 2 per CU (208 registers per lane), 16 x 16
+// tiles 3 per CU (168 registers; 33 KB of LDS each).
+constexpr unsigned kCpSlots32 = 2 * 256, kCpSlots16 = 3 * 256;
+// Pieces of the grid per tile: the fewest that make (tiles x pieces) at least six rounds over the `slots` resident
+// workgroups -- tiles differ in cost (a tile of degrees more than 2 apart takes 2 of the 21 instructions), so what evens the
+// chip out is many more workgroups than slots, not a whole number of rounds -- capped at 32 and at pieces of 24 chunks (192
+// points), below which the ring's fill (about five chunks' worth) starts to show.  Measured, tile 32
+// (profiles/r03_coupling_split_sweep.txt): M = 80 2.15 -> 0.21 ms (32 pieces), 240: 2.16 -> 0.70 (32), 512: 3.39 -> 2.04 (6)
+// | 2.08 (16), 1024: 8.34 -> 6.99 (3), 2048: 26.4 -> 25.6 (3) | 26.6 (16).
+inline unsigned cp_pieces(size_t tiles, unsigned slots, size_t n_chunks) {
+  const size_t most = std::max<size_t>(1, std::min<size_t>(32, n_chunks / 24));
+  const size_t want = (6 * size_t(slots) + tiles - 1) / std::max<size_t>(tiles, 1);
+  return (unsigned)std::min(most, std::max<size_t>(want, 1));
+}
+}  // namespace STORM_NS
+namespace storm {
+CouplingPlan plan_coupling_matrix(size_t n_pad, size_t n_pts, int matrix_tile, int split) {
+  using namespace storm_fast;
+  const size_t t16 = n_pad / 16, t32 = (n_pad + 31) / 32;
+  const size_t n_chunks = n_pts > 1 ? (n_pts - 1 + kCpChunk - 1) / kCpChunk : 1;
+  CouplingPlan plan;
+  // 32 x 32 tiles: half the staged bytes and a third fewer vector instructions per matrix instruction; with the grid cut
+  // into pieces the 16 x 16 walk's larger number of workgroups no longer counts for small problems
+  plan.tile = (matrix_tile == 16 || matrix_tile == 32) ? matrix_tile : 32;
+  plan.n_split = plan.tile == 32 ? cp_pieces(t32 * t32, kCpSlots32, n_chunks) : cp_pieces(t16 * t16, kCpSlots16, n_chunks);
+  if (split > 0) plan.n_split = (unsigned)std::min<size_t>(size_t(split), n_chunks);
+  return plan;
+}
+}  // namespace storm
+namespace STORM_NS {
+#endif
 
 hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
                                  hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile) {
@@ -953,8 +1009,17 @@ hipError_t launch_coupling(const CouplingArgs& a, int tile, int matrix_tile) {
   if (a.order) {  // the matrix-pipe walk over the ordered mode list takes all tiles
     const unsigned ptiles = (unsigned)(a.n_pad / 16), ptiles32 = (unsigned)((a.n_pad + 31) / 32);
     if (a.n_pad % 16 || ptiles == 0 || ptiles > 65535) return hipErrorInvalidValue;
-    if (cp_use_tiles32(size_t(ptiles32) * ptiles32, matrix_tile)) coupling_matrix_kernel<32><<<dim3(cp_grid_single(ptiles32), 1, 1), 256, 0, a.stream>>>(a);
-    else coupling_matrix_kernel<16><<<dim3(cp_grid_single(ptiles), 1, 1), 256, 0, a.stream>>>(a);
+    const size_t n_chunks = (a.n_pts - 1 + kCpChunk - 1) / kCpChunk;
+    if (a.n_split == 0 || a.n_split > n_chunks || (a.n_split > 1 && !a.partial) || (matrix_tile != 16 && matrix_tile != 32))
+      return hipErrorInvalidValue;   // (the caller passes plan_coupling_matrix's tile and pieces)
+    const unsigned per = cp_grid_single(matrix_tile == 32 ? ptiles32 : ptiles);
+    if (size_t(per) * a.n_split > 0x7fffffffu) return hipErrorInvalidValue;
+    if (matrix_tile == 32) coupling_matrix_kernel<32><<<dim3(per * a.n_split, 1, 1), 256, 0, a.stream>>>(a, per);
+    else coupling_matrix_kernel<16><<<dim3(per * a.n_split, 1, 1), 256, 0, a.stream>>>(a, per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.n_split == 1) return e;
+    const size_t n_out = size_t(kCouplingMatrices) * a.n_modes * a.n_modes;
+    coupling_pieces_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, a.stream>>>(a.partial, a.n_split, n_out, a.out, a.flags);
     return hipGetLastError();
   }
 #else

@@ -105,7 +105,19 @@ struct CouplingArgs {
   // is never padding.  nullptr: the vector walk (always in the parity build).
   const int* order = nullptr;
   size_t n_pad = 0;
+  // Matrix-pipe walk of ONE problem, split along the grid: workgroup (tile, piece) walks the piece's share of the points and
+  // writes its sums to partial[piece] (device [n_split][kCouplingMatrices][n_modes*n_modes]); a second launch adds the
+  // pieces in ascending order into `out` (deterministic).  n_split = 1: no split, the walk writes `out` itself.  From
+  // plan_coupling_matrix; what it buys: a tile count that is not a multiple of the chip's resident workgroups no longer
+  // leaves a mostly empty last round (M = 1024: 1089 tiles on 512 slots = 2.13 rounds paid as 3).
+  unsigned n_split = 1;
+  double* partial = nullptr;
 };
+
+// Tile (16 or 32) and number of pieces of the matrix-pipe walk for one problem of n_pad ordered positions on n_pts grid
+// points; matrix_tile / split: 0 = automatic, else forced (options "coupling_matrix_tile", "coupling_split").
+struct CouplingPlan { int tile; unsigned n_split; };
+CouplingPlan plan_coupling_matrix(size_t n_pad, size_t n_pts, int matrix_tile, int split);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.

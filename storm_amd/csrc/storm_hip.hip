@@ -247,7 +247,7 @@ struct storm_postproc {
   hipStream_t stream = nullptr;
   DevBuf<double> d_freq, d_vec, d_terms, d_scale, d_fields, d_nodes;
   DevBuf<long long> d_ids;
-  DevBuf<double> d_weights, d_consts, d_out;  // coupling integrals
+  DevBuf<double> d_weights, d_consts, d_out, d_partial;  // coupling integrals (d_partial: the pieces of a split walk)
   DevBuf<int> d_ell_index, d_cflags, d_order;
   DevBuf<long long> d_gather;                 // rows to pick out of a sweep's resident fields
   hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the coupling kernel
@@ -260,6 +260,7 @@ struct storm_postproc {
   int cp_tile = 0;                     // modes per side of a workgroup's tile of pairs: 0 = automatic, 8, 16 (option "coupling_tile")
   int cp_matrix = 1;                   // FMA build: 1 = the matrix-pipe walk over the ordered mode list, 0 = the vector walk (option "coupling_matrix")
   int cp_matrix_tile = 0;              // its tile: 0 = automatic, 16, 32 (option "coupling_matrix_tile")
+  int cp_split = 0;                    // pieces of the grid per tile: 0 = automatic (plan_coupling_matrix), k = forced (option "coupling_split")
   std::mutex mu;
 };
 
@@ -1383,7 +1384,7 @@ void storm_postproc_destroy(storm_postproc* p) {
   p->h_model.release();
   p->tab.release(); p->d_freq.release(); p->d_vec.release(); p->d_terms.release(); p->d_scale.release();
   p->d_fields.release(); p->d_nodes.release(); p->d_ids.release(); p->h_stage.release();
-  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release(); p->d_order.release(); p->d_gather.release();
+  p->d_weights.release(); p->d_consts.release(); p->d_out.release(); p->d_ell_index.release(); p->d_cflags.release(); p->d_order.release(); p->d_gather.release(); p->d_partial.release();
   (void)hipSetDevice(prev);
   delete p;
 }
@@ -1405,6 +1406,9 @@ int storm_postproc_set_option(storm_postproc* p, const char* key, int64_t value)
     } else if (k == "coupling_matrix_tile") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix_tile must be 0 (auto), 16 or 32");
       p->cp_matrix_tile = int(value);
+    } else if (k == "coupling_split") {
+      if (value < 0 || value > 64) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_split must be 0 (automatic) or 1..64 pieces");
+      p->cp_split = int(value);
     } else {
       fail(STORM_ERR_INVALID_ARGUMENT, "unknown option: " + k);
     }
@@ -1602,9 +1606,17 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     a.n_pts = np; a.n_modes = n; a.fields = p->d_fields.p; a.freq = p->d_freq.p; a.ell_index = p->d_ell_index.p;
     a.consts = p->d_consts.p; a.n_ell = int(ne); a.weights = p->d_weights.p; a.out = p->d_out.p; a.flags = p->d_cflags.p;
     a.rows = nullptr; a.stream = st;
+    int matrix_tile = p->cp_matrix_tile;
     if (!order.empty()) {
       hip_check(hipMemcpyAsync(p->d_order.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st), "order H2D");
       a.order = p->d_order.p; a.n_pad = order.size();
+      const storm::CouplingPlan plan = storm::plan_coupling_matrix(a.n_pad, np, p->cp_matrix_tile, p->cp_split);
+      matrix_tile = plan.tile;
+      a.n_split = plan.n_split;
+      if (plan.n_split > 1) {
+        p->d_partial.reserve(size_t(plan.n_split) * kCouplingMatrices * n * n, p->stream);
+        a.partial = p->d_partial.p;
+      }
     }
     if (coupling_has_sparse_pair(consts)) {
       a.tame = p->d_cflags.p + 1;
@@ -1613,7 +1625,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
     if (!p->ev0) hip_check(hipEventCreate(&p->ev0), "hipEventCreate");
     if (!p->ev1) hip_check(hipEventCreate(&p->ev1), "hipEventCreate");
     hip_check(hipEventRecord(p->ev0, st), "hipEventRecord");
-    hip_check((p->arith ? storm_fast::launch_coupling : storm::launch_coupling)(a, p->cp_tile ? p->cp_tile : coupling_tile_auto(n), p->cp_matrix_tile),
+    hip_check((p->arith ? storm_fast::launch_coupling : storm::launch_coupling)(a, p->cp_tile ? p->cp_tile : coupling_tile_auto(n), matrix_tile),
               "coupling launch");
     hip_check(hipEventRecord(p->ev1, st), "hipEventRecord");
     // results through pinned memory (a copy to pageable memory takes the runtime's staged, host-synchronous path)

@@ -273,18 +273,32 @@ def test_tiles_of_degrees_more_than_two_apart(oracle, oracle_models):
     mid2 = fl2.copy()
     mid2[3] *= 2.0 ** 150          # (2^150 is tame, 2^300 is not)
     ref3, _ = model.coupling_matrices(e2, f2, mid2, 1, metric, threads=16)
-    for mtile in (16, 32):
+    # ... and with the grid cut into pieces per tile (CouplingArgs::n_split: each piece's sums go to a scratch block, a second
+    # launch adds the pieces in ascending order): 0 = the library's plan (here 32 pieces), 1 = no split, odd counts
+    for mtile, split in ((16, 0), (32, 0), (16, 1), (32, 1), (32, 5), (16, 7), (16, 32)):
         post.set_option("coupling_matrix_tile", mtile)
+        post.set_option("coupling_split", split)
         fast2 = post.coupling_matrices(e2, f2, fl2, 1, metric)
+        again = post.coupling_matrices(e2, f2, fl2, 1, metric)
         for k in storm_amd.COUPLING_MATRICES:
             scale = np.max(np.abs(ref2[k]))
-            assert np.max(np.abs(fast2[k] - ref2[k])) <= 1e-12 * scale, (k, mtile, np.max(np.abs(fast2[k] - ref2[k])) / scale)
+            assert np.max(np.abs(fast2[k] - ref2[k])) <= 1e-12 * scale, (k, mtile, split, np.max(np.abs(fast2[k] - ref2[k])) / scale)
+            assert same_bits(fast2[k], again[k]), (k, mtile, split)       # the pieces are added in a fixed order
             if k != "l_zero":
-                assert np.all(fast2[k][far2] == 0.0) and not np.any(np.signbit(fast2[k][far2])), (k, mtile)
+                assert np.all(fast2[k][far2] == 0.0) and not np.any(np.signbit(fast2[k][far2])), (k, mtile, split)
         fast3 = post.coupling_matrices(e2, f2, mid2, 1, metric)
         for k in storm_amd.COUPLING_MATRICES:
-            assert np.max(np.abs(fast3[k] - ref3[k])) <= 1e-12 * np.max(np.abs(ref3[k])), (k, mtile)
+            assert np.max(np.abs(fast3[k] - ref3[k])) <= 1e-12 * np.max(np.abs(ref3[k])), (k, mtile, split)
     post.set_option("coupling_matrix_tile", 0)
+    post.set_option("coupling_split", 0)
+    # a non-finite field value in the FMA build: found in the final sums, also when they are sums of pieces
+    bad = fl2.copy()
+    bad[5, 4, 100] = np.inf      # (xi_r of mode 5 at one grid point)
+    for split in (1, 4):
+        post.set_option("coupling_split", split)
+        with pytest.raises(storm_amd.StormError, match="finite"):
+            post.coupling_matrices(e2, f2, bad, 1, metric)
+    post.set_option("coupling_split", 0)
     post.set_option("arithmetic", 0)
     # 12 modes per degree: the 16 x 16 tiles straddle the degree blocks, so the four waves of one workgroup take
     # different walks (all factors zero / different degrees / full expression) around the same staged chunks
