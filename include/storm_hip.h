@@ -393,6 +393,17 @@ int storm_solver_kernel_times(storm_solver* solver, double* ms_out, uint64_t* la
  *               segment length, -1 off, > 0 forced length.
  *               Tolerances as for "arithmetic" = 1; in this mode det_out of the eigenvector calls is the discriminant of
  *               the segment-boundary system (agrees with the reference's in magnitude to rounding, not in sign).
+ *   "scaled_scan": 1 = storm_scan_and_optimize, storm_scan_brackets and storm_optimize_brackets (and storm_multi_*, which
+ *                  is built on them) bracket on the scaled discriminant of storm_det_scaled_batch: the sign-swap filter
+ *                  takes the mantissa's sign, and every bracket is refined on values brought to one power of two of its
+ *                  own (InverseQuadratic::optimize, src/bracket.rs:148-223, is invariant under a common scaling of its
+ *                  three values), so a scan finds its modes where the reference's raw product has left the range of f64
+ *                  (src/solver.rs:504,531,541; src/dynamic_interface.rs:130-137 drops such pairs and reports invalid
+ *                  numbers).  Where the raw product is finite: the same bracket indices, roots equal to rounding
+ *                  (tests/test_hip_scaled_det.py).  det_out, lo_f and hi_f are mantissa * 2^exponent saturated to
+ *                  +-inf / +-0 -- the raw value where it exists; storm_optimize_brackets then takes only the SIGNS of
+ *                  lo_f / hi_f and evaluates both ends again.  0 (default): the reference's behaviour.  Evaluates
+ *                  through the staged step matrices: for large grids several times slower than the default scan.
  *   "profile": 1 records HIP events around every kernel launch (see storm_solver_kernel_times) */
 int storm_solver_set_option(storm_solver* solver, const char* key, int64_t value);
 

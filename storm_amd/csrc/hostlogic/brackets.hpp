@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../../include/storm_hip.h"
@@ -59,6 +60,8 @@ struct BracketState {
 // next abscissa (secant first, then inverse quadratic with secant fallback; ensure_maximal_bracket on the bit patterns),
 // `eval(xs, n, fs)` evaluates the n proposals in one batch, and each bracket replaces the end point of equal sign.
 // Per bracket this is the reference's loop, evaluation for evaluation (`evals` included).
+// `eval` may take a fourth argument, `const size_t* who`: the bracket each proposal belongs to (the scaled scan brings every
+// value to its bracket's own power of two).
 template <class Eval>
 void refine_brackets(std::vector<BracketState>& br, uint64_t ulp, Eval&& eval) {
   if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
@@ -86,7 +89,8 @@ void refine_brackets(std::vector<BracketState>& br, uint64_t ulp, Eval&& eval) {
     }
     if (xs.empty()) break;
     fs.resize(xs.size());
-    eval(xs.data(), xs.size(), fs.data());
+    if constexpr (std::is_invocable_v<Eval&, const double*, size_t, double*, const size_t*>) eval(xs.data(), xs.size(), fs.data(), who.data());
+    else eval(xs.data(), xs.size(), fs.data());
     for (size_t q = 0; q < who.size(); ++q) {
       BracketState& b = br[who[q]];
       const Pt next{xs[q], fs[q]};

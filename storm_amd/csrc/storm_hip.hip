@@ -200,6 +200,7 @@ struct storm_solver {
   DevBuf<int> d_bflags;
   PinnedBuf h_br;
   int device_brackets = 1;                       // 1 (default): sign-swap filter and refinement state machine on the device
+  int scaled_scan = 0;                           // 1: scans bracket on the scaled discriminant (mantissa, exponent): option "scaled_scan"
   int segments = 0;                              // 0 auto (FMA build only), -1 off, > 0 forced segment length
   double seg_growth_max = 16777216.0;            // 2^24: larger segment transfer matrices send a mode to the sequential path
   const double* h_freq_last = nullptr;           // the caller's frequencies of the eigenvector chunk in flight
@@ -998,6 +999,9 @@ int storm_solver_set_option(storm_solver* s, const char* key, int64_t value) {
       s->arith = int(value);
     } else if (k == "profile") {
       s->profile = value != 0;
+    } else if (k == "scaled_scan") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "scaled_scan must be 0 or 1");
+      s->scaled_scan = int(value);
     } else if (k == "device_brackets") {
       if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "device_brackets must be 0 (host state machine) or 1");
       s->device_brackets = int(value);
@@ -1077,34 +1081,40 @@ int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, doub
   });
 }
 
+// The discriminant as mantissa * 2^exponent for n host frequencies (caller holds the handle's lock, device current): step
+// matrices staged in chunks of steps_bytes_max, chain_kernel<.., SCALED> over them.
+static void det_scaled_locked(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
+  hipStream_t st = s->stream;
+  const size_t n_int = s->sys.n_int;
+  const size_t per_freq = std::max<size_t>(1, n_int) * 16 * sizeof(double);
+  size_t chunk = std::min<size_t>({n, std::max<size_t>(1, s->steps_bytes_max / per_freq), size_t(65535)});
+  s->d_freq.reserve(chunk, st); s->d_det.reserve(chunk, st);
+  s->d_bidx.reserve(chunk, st);  // (the exponents share the bracket-index buffer: 8 bytes per frequency)
+  steps_acquire(s, st);
+  s->steps_user = nullptr;
+  s->d_steps.reserve(chunk * n_int * 16 + 16, st);
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t m = std::min(chunk, n - off);
+    hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+    hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, st)), "build_steps launch");
+    hip_check((s->arith ? storm_fast::launch_chain_scaled : storm::launch_chain_scaled)(
+                  s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_det.p, reinterpret_cast<long long*>(s->d_bidx.p), st),
+              "chain launch");
+    count_launch(s, 2);
+    hip_check(hipMemcpyAsync(mantissa_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, st), "mantissa D2H");
+    hip_check(hipMemcpyAsync(exponent_out + off, s->d_bidx.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st), "exponent D2H");
+    check_flags(s);  // synchronises
+  }
+  s->stats.det_evals += n;
+}
+
 int storm_det_scaled_batch(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
   return guarded([&] {
     if (!s || (n && (!freq || !mantissa_out || !exponent_out))) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return;
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard g(s->device);
-    hipStream_t st = s->stream;
-    const size_t n_int = s->sys.n_int;
-    const size_t per_freq = std::max<size_t>(1, n_int) * 16 * sizeof(double);
-    size_t chunk = std::min<size_t>({n, std::max<size_t>(1, s->steps_bytes_max / per_freq), size_t(65535)});
-    s->d_freq.reserve(chunk, st); s->d_det.reserve(chunk, st);
-    s->d_bidx.reserve(chunk, st);  // (the exponents share the bracket-index buffer: 8 bytes per frequency)
-    steps_acquire(s, st);
-    s->steps_user = nullptr;
-    s->d_steps.reserve(chunk * n_int * 16 + 16, st);
-    for (size_t off = 0; off < n; off += chunk) {
-      const size_t m = std::min(chunk, n - off);
-      hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
-      hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, st)), "build_steps launch");
-      hip_check((s->arith ? storm_fast::launch_chain_scaled : storm::launch_chain_scaled)(
-                    s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_det.p, reinterpret_cast<long long*>(s->d_bidx.p), st),
-                "chain launch");
-      count_launch(s, 2);
-      hip_check(hipMemcpyAsync(mantissa_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, st), "mantissa D2H");
-      hip_check(hipMemcpyAsync(exponent_out + off, s->d_bidx.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st), "exponent D2H");
-      check_flags(s);  // synchronises
-    }
-    s->stats.det_evals += n;
+    det_scaled_locked(s, freq, n, mantissa_out, exponent_out);
   });
 }
 
@@ -1228,11 +1238,104 @@ static void scan_on_device(storm_solver* s, const double* freq, size_t n, bool r
   }
 }
 
+// ---- Option "scaled_scan": bracketing on the scaled discriminant (north_star's "running log-determinant") ----
+// The reference multiplies the raw step matrices (src/solver.rs:504,531,541) and can only notice afterwards that the product
+// left the range of f64 (src/dynamic_interface.rs:130-137: the pair is dropped, the scan reports invalid numbers).  With
+// this option a scan evaluates mantissa * 2^exponent instead (det_scaled_locked): the sign-swap filter needs the sign
+// only, and InverseQuadratic::optimize is invariant under a common scaling of its three values, so every bracket works on
+// values brought to ONE power of two of its own, E = the larger exponent of its two ends (exact scalings: where the raw
+// product is finite the proposals are the raw run's up to the rounding of the closing elimination).
+// Values handed back (det_out, lo_f, hi_f) are mantissa * 2^exponent saturated to +-inf / +-0: the raw value where it exists.
+inline double saturating_ldexp(double m, int64_t e) {
+  if (m == 0.0 || m != m) return m;
+  if (e > 2000) return std::signbit(m) ? -std::numeric_limits<double>::infinity() : std::numeric_limits<double>::infinity();
+  if (e < -2200) return std::signbit(m) ? -0.0 : 0.0;
+  return std::ldexp(m, int(e));
+}
+// value on a bracket's scale: exponent differences beyond +-1000 are clamped (the sign survives, which is what keeps the
+// bracket a bracket; the interpolation then degrades to a bisection-like step instead of meeting an infinity)
+inline double on_scale(double m, int64_t e, int64_t scale) {
+  const int64_t d = std::max<int64_t>(-1000, std::min<int64_t>(1000, e - scale));
+  return std::ldexp(m, int(d));
+}
+static void refine_scaled(storm_solver* s, std::vector<BracketState>& br, const std::vector<int64_t>& scale, uint64_t ulp) {
+  std::vector<double> mant;
+  std::vector<int64_t> expo;
+  refine_brackets(br, ulp, [&](const double* xs, size_t n, double* fs, const size_t* who) {
+    mant.resize(n); expo.resize(n);
+    det_scaled_locked(s, xs, n, mant.data(), expo.data());
+    s->stats.det_evals -= n;   // (counted as refinement evaluations, like the raw path's)
+    for (size_t q = 0; q < n; ++q) fs[q] = on_scale(mant[q], expo[q], scale[who[q]]);
+    s->stats.refine_evals += n;
+    s->stats.refine_rounds += 1;
+  });
+}
+static void scan_scaled(storm_solver* s, const double* freq, size_t n, bool refine, uint64_t ulp, storm_bracket* out,
+                        size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
+  if (n == 0) return;
+  std::vector<double> mant(n);
+  std::vector<int64_t> expo(n);
+  det_scaled_locked(s, freq, n, mant.data(), expo.data());
+  if (det_out)
+    for (size_t i = 0; i < n; ++i) det_out[i] = saturating_ldexp(mant[i], expo[i]);
+  std::vector<BracketState> br;
+  std::vector<uint64_t> idx;
+  bool invalid = false;
+  filter_sign_swaps(freq, mant.data(), n, br, idx, invalid);   // (a NaN mantissa is a NaN discriminant: dropped and reported)
+  if (had_invalid) *had_invalid = invalid ? 1 : 0;
+  *n_out = br.size();
+  if (br.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+  std::vector<int64_t> scale(br.size());
+  for (size_t k = 0; k < br.size(); ++k) {
+    if (!std::isfinite(br[k].lower.x) || !std::isfinite(br[k].upper.x)) fail(STORM_ERR_BRACKET, "non-finite scan frequency");
+    const size_t i = size_t(idx[k]);
+    scale[k] = std::max(expo[i], expo[i + 1]);
+    br[k].lower.f = on_scale(mant[i], expo[i], scale[k]);
+    br[k].upper.f = on_scale(mant[i + 1], expo[i + 1], scale[k]);
+  }
+  if (refine) refine_scaled(s, br, scale, ulp);
+  for (size_t k = 0; k < br.size(); ++k) {
+    out[k] = storm_bracket{br[k].lower.x, saturating_ldexp(br[k].lower.f, scale[k]), br[k].upper.x, saturating_ldexp(br[k].upper.f, scale[k]),
+                           refine ? br[k].root : std::numeric_limits<double>::quiet_NaN(), br[k].evals};
+    if (index_out) index_out[k] = idx[k];
+  }
+}
+// storm_optimize_brackets under "scaled_scan": the end values may be infinite (saturated), so only their signs are taken
+// from the caller and both ends are evaluated again (one batch) to put them on the bracket's scale.
+static void optimize_scaled(storm_solver* s, storm_bracket* brackets, size_t n, uint64_t ulp) {
+  std::vector<double> xs(2 * n), mant(2 * n);
+  std::vector<int64_t> expo(2 * n);
+  for (size_t k = 0; k < n; ++k) {
+    const storm_bracket& b = brackets[k];
+    if (!std::isfinite(b.lo_x) || !std::isfinite(b.hi_x)) fail(STORM_ERR_BRACKET, "bracket end points must be finite");
+    if (b.lo_f != b.lo_f || b.hi_f != b.hi_f || sign_of(b.lo_f) == sign_of(b.hi_f)) fail(STORM_ERR_BRACKET, "bracket end values must differ in sign");
+    xs[2 * k] = b.lo_x; xs[2 * k + 1] = b.hi_x;
+  }
+  det_scaled_locked(s, xs.data(), 2 * n, mant.data(), expo.data());
+  std::vector<BracketState> br(n);
+  std::vector<int64_t> scale(n);
+  for (size_t k = 0; k < n; ++k) {
+    if (sign_of(mant[2 * k]) != sign_of(brackets[k].lo_f) || sign_of(mant[2 * k + 1]) != sign_of(brackets[k].hi_f))
+      fail(STORM_ERR_BRACKET, "bracket end values do not have the signs of the discriminant at the end points");
+    scale[k] = std::max(expo[2 * k], expo[2 * k + 1]);
+    br[k].lower = Pt{xs[2 * k], on_scale(mant[2 * k], expo[2 * k], scale[k])};
+    br[k].upper = Pt{xs[2 * k + 1], on_scale(mant[2 * k + 1], expo[2 * k + 1], scale[k])};
+  }
+  refine_scaled(s, br, scale, ulp);
+  for (size_t k = 0; k < n; ++k)
+    brackets[k] = storm_bracket{br[k].lower.x, saturating_ldexp(br[k].lower.f, scale[k]), br[k].upper.x,
+                                saturating_ldexp(br[k].upper.f, scale[k]), br[k].root, br[k].evals};
+}
+
 static void scan_impl(storm_solver* s, const double* freq, size_t n, bool refine, uint64_t ulp, storm_bracket* out,
                       size_t cap, size_t* n_out, int* had_invalid, double* det_out, uint64_t* index_out) {
   if (!s || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
   std::lock_guard<std::mutex> lock(s->mu);
   DeviceGuard g(s->device);
+  if (s->scaled_scan) {
+    scan_scaled(s, freq, n, refine, ulp, out, cap, n_out, had_invalid, det_out, index_out);
+    return;
+  }
   if (s->device_brackets) {
     scan_on_device(s, freq, n, refine, ulp, out, cap, n_out, had_invalid, det_out, index_out);
     return;
@@ -1279,6 +1382,10 @@ int storm_optimize_brackets(storm_solver* s, storm_bracket* brackets, size_t n, 
     if (n == 0) return;
     std::lock_guard<std::mutex> lock(s->mu);
     DeviceGuard g(s->device);
+    if (s->scaled_scan) {
+      optimize_scaled(s, brackets, n, ulp);
+      return;
+    }
     std::vector<BracketState> br(n);
     for (size_t k = 0; k < n; ++k) {
       const storm_bracket& b = brackets[k];
