@@ -12,8 +12,10 @@ value = (frequency x interval) discriminant evaluations per second over the whol
 the numerator, everything incl. eigenvectors in the denominator), summed over all ranks.
 
 N > 1 is STRONG scaling: the same 10^5-point grid is cut into N contiguous slices (+1 halo point), one per rank/GPU;
-sign-swap brackets are gathered over RCCL, dealt out cyclically for refinement + eigenvectors, and gathered again
-(storm_amd/distributed.py: strong_scan_and_optimize).
+every rank scans and refines its slice in one library call, then the refined brackets are gathered over RCCL (ONE
+all_gather, in flight while the rank computes the eigenvectors of its own modes; storm_amd/distributed.py:
+strong_scan_and_optimize(deal=False) -- the two-collective protocol that deals the brackets out cyclically is its
+deal=True).
 
 Both arithmetic builds run in the same invocation.  The headline is the FMA build ("fast": v_fma_f64 allowed; results
 agree with the reference to rounding, north_star's own contract: bracket indices bit-identical -- asserted below on the
@@ -245,10 +247,10 @@ def main():
             res, _, _ = h.scan_and_optimize(freqs, ulp, cap=8192, want_dets=False)  # (the reference returns brackets only)
             eigenvectors(res)
             return res
-        # N > 1 (and the phase-timing pass at N = 1): the two halves as separate calls with the gathers in between;
-        # brackets travel as record arrays (no per-bracket Python inside the step)
+        # N > 1: scan + refinement of the slice in one call, one gather overlapped with the eigenvectors; brackets travel as
+        # record arrays (no per-bracket Python inside the step).  (The phase-timing pass at N = 1: the two-call form.)
         res, _, _ = D.strong_scan_and_optimize(h, freqs, ulp, device=coll_device, after_refine=eigenvectors,
-                                               timings=timings, records=True)
+                                               timings=timings, records=True, deal=False)
         return res
 
     # Before anything is timed: the FMA build must find the parity build's brackets, index for index, on the full grid.
@@ -367,11 +369,12 @@ def main():
     res = measure(main_arith, args.steps, args.warmup)
 
     def phase_times(steps=5):
-        """Where a step goes, per rank: the scan of the rank's slice, the gather of the unrefined brackets, the refinement of
-        the brackets dealt to the rank, their eigenvectors, the gather of the refined records (host clock around each
-        phase inside strong_scan_and_optimize, every phase ends synchronised).  At N = 1 the two gathers do not exist and
-        the step is the two-call form of the scan (storm_scan_brackets, storm_optimize_brackets), not the one-call form
-        `value` is measured on.  Returns rank 0's figures and the maximum over the ranks, ms per step."""
+        """Where a step goes, per rank (host clock around each phase inside strong_scan_and_optimize).  N > 1: slice_scan =
+        scan + refinement of the rank's slice (one library call), eigenvectors = this rank's modes, computed while the one
+        all_gather is in flight, gather_refined = what is left to wait for (it contains the wait for the slowest rank);
+        gather_found and refine are 0 in this protocol.  N = 1: no gather, and the step is the two-call form of the scan
+        (storm_scan_brackets, storm_optimize_brackets), not the one-call form `value` is measured on.  Returns rank 0's
+        figures and the maximum over the ranks, ms per step."""
         h.set_option("arithmetic", main_arith)
         one_scan(timings={})
         t = {}
@@ -430,12 +433,19 @@ def main():
                 "value": st["det_evals"] * n_int / dt, "unit": "freq*interval evals/s",
                 "bracket_indices_equal_headline": indices_of(res) == idx_f}
 
-    # While rank 0 drives all N devices the other ranks wait on the HOST (a gloo group): a barrier of the GPU backend would
-    # keep a spinning kernel on every device the leg is about to time.
-    host_group = dist.new_group(backend="gloo") if world > 1 and args.dist_backend == "nccl" else None
+    # While rank 0 drives all N devices the other ranks wait on the HOST (a key in the rendezvous store): a barrier of the
+    # GPU backend would keep a spinning kernel on every device the leg is about to time.
     multi = leg(multi_in_library) if rank == 0 else None
     if world > 1:
-        dist.barrier(group=host_group)
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("storm_multi_leg_done", "1")
+            else:
+                store.wait(["storm_multi_leg_done"])
+        except Exception:  # noqa: BLE001 (no store to wait on: the backend's own barrier, kernels and all)
+            pass
+        dist.barrier()
     h.set_option("arithmetic", 0)
 
     def eigen_roofline():
@@ -472,7 +482,7 @@ def main():
                                    "Colloc4, scan linspace(1,25,10^5) at precision 1e-8 + eigenvector per mode "
                                    "(= StormState::scan, src/main.rs:793-838)",
                        "n_freq_total": N_FREQ, "n_int": n_int, "scheme": "colloc4", "ell": 2,
-                       "parallelism": f"one 10^5-point grid cut into {world} contiguous slice(s), brackets dealt cyclically"},
+                       "parallelism": f"one 10^5-point grid cut into {world} contiguous slice(s), brackets refined where found, one all_gather"},
             "arithmetic": name_main,
             "modes_per_s": res["eigs"] / res["elapsed"], "modes_per_step": res["modes"],
             "det_evals": res["det_evals"], "refine_evals": res["refine"],

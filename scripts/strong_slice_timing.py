@@ -35,3 +35,20 @@ for G in (1, 2, 4, 8):
                 best = row
     print(f"G={G}: slowest rank {best[0]*1e3:.2f} ms per step (scan of the slice {best[1]*1e3:.2f}, refinement {best[2]*1e3:.2f}, "
           f"eigenvectors {best[3]*1e3:.2f}) -> {1e5 * es.n_int / best[0] / 1e10:.2f}e10 evals/s without the two collectives", flush=True)
+    # the one-collective protocol (strong_scan_and_optimize(deal=False), what bench.py --gpus N runs): scan + refinement of
+    # the slice in ONE library call, then the eigenvectors of the slice's own modes
+    own = None
+    for rank in range(G):
+        lo, mine = D.local_slice(freqs, G, rank)
+        for rep in range(4):
+            t0 = time.perf_counter()
+            rec, _ = h.scan_and_optimize_records(mine, ulp, lo)
+            t1 = time.perf_counter()
+            if rec.shape[0]:
+                h.eigenvector(rec[:, 4].copy(), out=buf)
+            t2 = time.perf_counter()
+            row = (t2 - t0, t1 - t0, t2 - t1, rec.shape[0])
+            if rep and (own is None or row[0] > own[0]):
+                own = row
+    print(f"G={G}: one-collective protocol: slowest rank {own[0]*1e3:.2f} ms per step (scan + refinement of the slice {own[1]*1e3:.2f}, "
+          f"eigenvectors of its {own[3]} modes {own[2]*1e3:.2f}) -> {1e5 * es.n_int / own[0] / 1e10:.2f}e10 evals/s without the collective", flush=True)

@@ -58,20 +58,31 @@ class _Exchange:
         self.parts = None
         self.send_np, self.recv_np = self.h_send.numpy(), self.h_recv.numpy()
 
-    def run(self):
-        """all_gather of send_np (filled by the caller) -> recv_np [world, *shape]"""
+    def start(self):
+        """Puts the all_gather of send_np (filled by the caller) in flight and returns: host work done before finish()
+        -- the eigenvectors of this rank's modes on the solver's own stream -- overlaps the exchange."""
         if self.on_gpu:
             self.send.copy_(self.h_send, non_blocking=True)
         if _single_tensor_form():
-            dist.all_gather_into_tensor(self.recv, self.send)
+            self.work = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
         else:
             if self.parts is None:
                 self.parts = list(self.recv.unbind(0))   # views into recv: the list form writes in place
-            dist.all_gather(self.parts, self.send)
+            self.work = dist.all_gather(self.parts, self.send, async_op=True)
+
+    def finish(self):
+        """-> recv_np [world, *shape] of the exchange start() put in flight"""
+        self.work.wait()     # (a GPU backend: torch's current stream waits for the collective's)
+        self.work = None
         if self.on_gpu:
             self.h_recv.copy_(self.recv, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
         return self.recv_np
+
+    def run(self):
+        """all_gather of send_np (filled by the caller) -> recv_np [world, *shape]"""
+        self.start()
+        return self.finish()
 
 
 _EXCHANGES = {}
@@ -107,18 +118,22 @@ def _all_gather_rows(buf, device):
     return ex.run()
 
 
-def gather_brackets(local_records, invalid, device):
+def gather_brackets(local_records, invalid, device, meanwhile=None):
     """all_gather of per-rank bracket records -> (global records in ascending order, any_invalid).
 
     ONE collective in the usual case: every rank sends GATHER_CAP padded records behind a header row (count, invalid
-    flag); only if some rank found more is a second exchange made, sized by the largest count."""
+    flag); only if some rank found more is a second exchange made, sized by the largest count.  `meanwhile()` runs while
+    the first exchange is in flight."""
     n = local_records.shape[0]
     ex = _exchange(device, (GATHER_CAP + 1, RECORD))
     buf = ex.send_np
     buf[0, 0], buf[0, 1] = float(n), 1.0 if invalid else 0.0
     if n:
         buf[1:1 + min(n, GATHER_CAP)] = local_records[:GATHER_CAP]
-    got = ex.run()
+    ex.start()
+    if meanwhile is not None:
+        meanwhile()
+    got = ex.finish()
     counts = got[:, 0, 0].astype(np.int64)
     any_invalid = bool(got[:, 0, 1].any())
     if counts.max(initial=0) > GATHER_CAP:
@@ -157,20 +172,32 @@ def deal(n_brackets, world, rank):
 PHASES = ("slice_scan", "gather_found", "refine", "after_refine", "gather_refined")
 
 
-def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None, timings=None, records=False):
+def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None, timings=None, records=False, deal=True):
     """scan_and_optimize of ONE frequency grid split over the ranks of the default process group (strong scaling).
 
-    Every rank evaluates a contiguous slice (+1 halo point) and finds its sign swaps (`solver.scan_brackets`); the
-    unrefined brackets are gathered (one all_gather of padded records behind a header row), dealt out cyclically, refined
-    where they were dealt (`solver.optimize_brackets`), and the refined records are gathered again (one all_gather: the
-    deal fixes every rank's count).  `after_refine(my_brackets)` runs between refinement and the last gather (the
-    eigenvectors of this rank's modes).  Returns (all brackets in ascending order, any_invalid, this rank's brackets) --
-    lists of dicts, or with `records` the [n, RECORD] arrays themselves (no per-bracket Python at all).
-    `timings`: a dict that receives this rank's seconds per phase (PHASES), accumulated over calls.
+    Every rank evaluates a contiguous slice (+1 halo point) and finds its sign swaps.  Then one of two protocols:
+
+    deal=True: the unrefined brackets are gathered (one all_gather of padded records behind a header row),
+    dealt out cyclically, refined where they were dealt (`solver.optimize_brackets`), and the refined records are gathered
+    again (one all_gather: the deal fixes every rank's count); `after_refine(my_brackets)` runs between refinement and
+    the last gather (the eigenvectors of this rank's modes).  Two collectives; a slice that is dense in modes does not
+    serialise on the rank that scanned it.
+
+    deal=False: every rank refines the brackets of its own slice in the same library call that scanned it
+    (`solver.scan_and_optimize`: nothing crosses PCIe between the scan and the refinement), then ONE all_gather of the
+    refined records, in flight while `after_refine(my_brackets)` computes this rank's eigenvectors.  One collective and no
+    wait between scan and refinement: what a scan with a few dozen modes wants (refinement rounds and eigenvectors are
+    latency-bound: their time hardly depends on how many brackets a rank holds).  Same records either way, bit for bit.
+
+    Returns (all brackets in ascending order, any_invalid, this rank's brackets) -- lists of dicts, or with `records` the
+    [n, RECORD] arrays themselves (no per-bracket Python at all).  `timings`: a dict that receives this rank's seconds per
+    phase (PHASES), accumulated over calls (deal=False: slice_scan includes the refinement, after_refine runs inside
+    gather_refined's flight and is listed on its own, gather_refined is what is left to wait for).
 
     `solver` needs .scan_brackets(freqs) -> (brackets with 'index', dets, invalid) and
-    .optimize_brackets(brackets, ulp) -> brackets; if it has .scan_brackets_records / .optimize_records (ffi.HipSolver)
-    those are used instead and the records go from the C struct array to the exchange buffer as numpy columns."""
+    .optimize_brackets(brackets, ulp) -> brackets (deal=False: .scan_and_optimize(freqs, ulp) -> the same triple, refined);
+    if it has the *_records forms (ffi.HipSolver) those are used instead and the records go from the C struct array to the
+    exchange buffer as numpy columns."""
     import time
     freqs = np.ascontiguousarray(freqs, dtype=np.float64)
     fast = hasattr(solver, "scan_brackets_records") and hasattr(solver, "optimize_records")
@@ -210,6 +237,26 @@ def strong_scan_and_optimize(solver, freqs, ulp, device="cpu", after_refine=None
         return out, inv, out
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, mine = local_slice(freqs, world, rank)
+    if not deal:
+        if len(mine) < 2:
+            my, inv = np.zeros((0, RECORD)), False
+        elif hasattr(solver, "scan_and_optimize_records"):
+            my, inv = solver.scan_and_optimize_records(mine, ulp, lo)
+        else:
+            res, _, inv = solver.scan_and_optimize(mine, ulp)
+            my = pack(res, lo)
+        lap("slice_scan")
+        my_out = give(my)
+
+        def eigenvectors():
+            lap("gather_refined")      # (the few microseconds of putting the exchange in flight)
+            if after_refine is not None:
+                after_refine(my_out)
+            lap("after_refine")
+
+        out, any_inv = gather_brackets(my, inv, device, meanwhile=eigenvectors)
+        lap("gather_refined")
+        return give(out), any_inv, my_out
     found, inv = scan(mine, lo)
     lap("slice_scan")
     rec, any_inv = gather_brackets(found, inv, device)

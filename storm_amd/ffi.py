@@ -171,6 +171,9 @@ def kernel_times(handle, reset=False):
     return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
 
 
+STORM_ERR_CAPACITY = -5   # include/storm_hip.h: output buffer too small; *n_out holds the required count
+
+
 def _check(rc):
     if rc != 0:
         raise StormError(rc, load_library().storm_last_error().decode())
@@ -309,6 +312,29 @@ class HipSolver:
 
     # ---- the same two calls on record arrays (storm_amd.distributed: rows of RECORD float64 columns lo_x, lo_f, hi_x, hi_f,
     # root, evals, global index), packed and unpacked through numpy views of the C struct array: no per-bracket Python
+    def scan_and_optimize_records(self, freqs, ulp, offset=0, cap=None):
+        """storm_scan_and_optimize -> (refined records [n, 7], invalid); `offset` is added to the bracket indices (a slice's
+        position in the whole grid).  The discriminants of the grid stay on the device."""
+        f = _f64(freqs)
+        cap = min(max(1, f.size), 8192) if cap is None else cap
+        while True:
+            out = (Bracket * max(cap, 1))()
+            idx = (C.c_uint64 * max(cap, 1))()
+            n_out, inv = C.c_size_t(0), C.c_int(0)
+            rc = load_library().storm_scan_and_optimize(self._h, _p(f), f.size, ulp, out, cap, C.byref(n_out), C.byref(inv), None, idx)
+            if rc == STORM_ERR_CAPACITY and cap < max(n_out.value, 1):   # (more modes than room: once more, with the count it reported)
+                cap = n_out.value
+                continue
+            _check(rc)
+            break
+        n = n_out.value
+        rec = np.empty((n, 7))
+        b = np.frombuffer(out, dtype=BRACKET_DTYPE, count=n)
+        for k, name in enumerate(("lo_x", "lo_f", "hi_x", "hi_f", "root", "evals")):
+            rec[:, k] = b[name]
+        rec[:, 6] = np.frombuffer(idx, dtype=np.uint64, count=n).astype(np.float64) + float(offset)
+        return rec, bool(inv.value)
+
     def scan_brackets_records(self, freqs, offset=0, cap=None):
         """storm_scan_brackets -> (records [n, 7], invalid); `offset` is added to the bracket indices (a slice's position in
         the whole grid).  The discriminants of the grid stay on the device."""

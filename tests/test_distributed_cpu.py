@@ -114,6 +114,57 @@ def test_strong_scaling_scan_deals_brackets_and_matches_single_process(tmp_path,
     assert sorted(dealt) == [b["index"] for b in ref]  # every bracket refined by exactly one rank
 
 
+class _OracleWhole(_OracleHalves):
+    """... plus the one-call form the deal=False protocol takes (scan and refinement of a slice in one go)."""
+
+    def scan_and_optimize(self, freqs, ulp):
+        found, dets, inv = self.scan_brackets(freqs)
+        return self.optimize_brackets(found, ulp), dets, inv
+
+
+def _owner_worker(rank, world, port, n_freq, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import storm_ref
+    from storm_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = storm_ref.Model.from_gsm_npz(os.path.join(ROOT, "tests", "golden", "gsm_zams.npz"))
+        solver = _OracleWhole(storm_ref.Solver(model, 1, 0, "colloc2", model.field("r_coord")))
+        freqs = storm_ref.linspace(1.0, 25.0, n_freq)
+        timings = {}
+        for records in (False, True):
+            seen = []
+            res, inv, mine = D.strong_scan_and_optimize(solver, freqs, 1, device="cpu", after_refine=seen.append, timings=timings,
+                                                        records=records, deal=False)
+            assert len(seen) == 1 and seen[0] is mine      # the eigenvector hook ran once, on this rank's own brackets
+        assert set(timings) <= set(D.PHASES) and {"slice_scan", "after_refine", "gather_refined"} <= set(timings)
+        np.save(os.path.join(out_dir, f"own{rank}.npy"), res)
+        np.save(os.path.join(out_dir, f"ownmine{rank}.npy"), mine)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_freq", [(2, 80), (3, 41), (2, 3), (3, 2)])
+def test_strong_scaling_owner_refines_one_collective(tmp_path, oracle, oracle_models, world, n_freq):
+    """deal=False: every rank refines what its slice found and ONE all_gather (in flight during the eigenvector hook) puts
+    the list together: the single-process record array on every rank, bit for bit, and each rank's own part of it."""
+    from storm_amd import distributed as D
+    port = 37500 + (os.getpid() % 2000) + world + n_freq
+    mp.spawn(_owner_worker, args=(world, port, n_freq, str(tmp_path)), nprocs=world, join=True)
+    model = oracle_models("zams")
+    solver = oracle.Solver(model, 1, 0, "colloc2", model.field("r_coord"))
+    ref, _, _ = solver.scan_and_optimize(oracle.linspace(1.0, 25.0, n_freq), 1, threads=8)
+    ref_rec = D.pack(ref, 0)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"own{r}.npy").view(np.uint64), ref_rec.view(np.uint64)), f"rank {r}"
+        lo, hi = D.shard_bounds(n_freq, world, r)
+        part = ref_rec[(ref_rec[:, 6] >= lo) & (ref_rec[:, 6] < hi)]
+        assert np.array_equal(np.load(tmp_path / f"ownmine{r}.npy").view(np.uint64), part.view(np.uint64)), f"rank {r}"
+
+
 class _OracleRecords(_OracleHalves):
     """... and for ffi.HipSolver.scan_brackets_records / optimize_records (the array form the RCCL path takes)."""
 

@@ -332,9 +332,12 @@ def _strong_hip_worker(rank, world, port, backend, out_dir):
             if brackets:
                 vecs.append(h.eigenvector(np.array([b["root"] for b in brackets]))[1])
 
-        res, inv, mine = D.strong_scan_and_optimize(h, f, ffi.relative_to_ulp(1e-8),
-                                                    device=torch.device("cuda", dev) if backend == "nccl" else "cpu",
-                                                    after_refine=eig)
+        where = torch.device("cuda", dev) if backend == "nccl" else "cpu"
+        # deal=False first (one collective, every rank refines its own slice's brackets; its eigenvectors are not kept)
+        own, inv1, own_mine = D.strong_scan_and_optimize(h, f, ffi.relative_to_ulp(1e-8), device=where, records=True, deal=False)
+        np.save(os.path.join(out_dir, f"own{rank}.npy"), own)
+        np.save(os.path.join(out_dir, f"ownmine{rank}.npy"), own_mine)
+        res, inv, mine = D.strong_scan_and_optimize(h, f, ffi.relative_to_ulp(1e-8), device=where, after_refine=eig)
         np.save(os.path.join(out_dir, f"hip{rank}.npy"), D.pack(res, 0))
         np.save(os.path.join(out_dir, f"vec{rank}.npy"), vecs[0] if vecs else np.zeros((0, 0)))
         np.save(os.path.join(out_dir, f"idx{rank}.npy"), np.array([b["index"] for b in mine], dtype=np.int64))
@@ -364,6 +367,10 @@ def test_strong_scaling_with_hip_on_every_rank(tmp_path, oracle, oracle_models):
         share = D.deal(len(ref), world, r)
         assert np.load(tmp_path / f"idx{r}.npy").tolist() == [ref[k]["index"] for k in share]
         assert same_bits(np.load(tmp_path / f"vec{r}.npy"), rvec[share])
+        # the one-collective protocol: the same list on every rank, and the rank's own slice's part of it
+        assert same_bits(np.load(tmp_path / f"own{r}.npy"), ref_rec), f"rank {r}"
+        lo, hi = D.shard_bounds(4000, world, r)
+        assert same_bits(np.load(tmp_path / f"ownmine{r}.npy"), ref_rec[(ref_rec[:, 6] >= lo) & (ref_rec[:, 6] < hi)]), f"rank {r}"
 
 
 def test_exchange_path_over_rccl_one_rank():
