@@ -307,12 +307,16 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* sweep, size_t n_problems, s
  * scan_and_optimize (src/dynamic_interface.rs:116-160): device k evaluates the contiguous slice
  * [k*ceil(n/n_dev), (k+1)*ceil(n/n_dev)) plus ONE halo point, so every adjacent pair is owned by exactly one device; the
  * sign-swap brackets (a few KB) are gathered in host memory in ascending order -- the reference's single global
- * filter_sign_swap order (src/bracket.rs:236-250); no collective library is involved inside one process -- and dealt out
- * cyclically by global bracket index for the refinement (src/dynamic_interface.rs:139-151), so that a slice dense in
- * modes does not serialise on the device that scanned it.  storm_multi_eigenvector_batch deals the modes the same way.
- * Results are bit-identical to one storm_solver on one device (every evaluation runs the same kernels).  `devices` may
- * list a device more than once (it then runs several slices; used to test the logic on one GPU).  Options are
- * forwarded to every solver.  One process per GPU over RCCL instead: storm_amd/distributed.py (same split, same deal). */
+ * filter_sign_swap order (src/bracket.rs:236-250); no collective library is involved inside one process.  Refinement
+ * (src/dynamic_interface.rs:139-151): by default every device refines the brackets of its own slice in the call that
+ * scanned it (one round of host threads, nothing between scan and refinement: refinement rounds are latency-bound
+ * whatever the count); option "deal" = 1 deals the gathered brackets out cyclically by global bracket index instead, so
+ * that a slice dense in modes (hundreds) does not serialise on the device that scanned it.
+ * storm_multi_eigenvector_batch deals the modes cyclically.
+ * Results are bit-identical to one storm_solver on one device either way (every evaluation runs the same kernels).
+ * `devices` may list a device more than once (it then runs several slices; used to test the logic on one GPU).  Every
+ * other option is forwarded to every solver.  One process per GPU over RCCL instead: storm_amd/distributed.py (same
+ * split, the same two protocols: strong_scan_and_optimize(deal=False | True)). */
 typedef struct storm_multi storm_multi;
 int storm_multi_create(const storm_system_desc* desc, const int* devices, size_t n_dev, storm_multi** out);
 void storm_multi_destroy(storm_multi* multi);

@@ -10,6 +10,7 @@
 //   int scan_brackets(Solver, const double* freq, size_t n, storm_bracket* out, size_t cap, size_t* n_out, int* invalid,
 //                     double* det_out, uint64_t* index_out);          (status codes of storm_hip.h)
 //   int optimize_brackets(Solver, storm_bracket* br, size_t n, uint64_t ulp);
+//   int scan_and_optimize(Solver, ... as scan_brackets, with `uint64_t ulp` after n ...);   (the two in one call)
 //   int eigenvector_batch(Solver, const double* freq, size_t n, double* det_out, double* vec_out);
 //   size_t n_int(Solver);
 //   std::string last_error();                                         (of the calling thread)
@@ -64,12 +65,21 @@ void on_every_device(size_t n, Job&& job, LastError&& last_error) {
 }
 
 // ErasedSolver::scan_and_optimize (src/dynamic_interface.rs:116-160) over the solvers of D devices.
+// deal = false (default of a storm_multi): every device refines the brackets of its own slice in the call that scanned it --
+// one round of host threads, nothing between scan and refinement; what a scan with a few dozen modes wants (refinement
+// rounds are latency-bound whatever the count).  deal = true: SURVEY 8(e)'s protocol -- scan, gather, deal the brackets
+// cyclically, refine -- for a grid whose modes crowd into one slice.  Same brackets either way, bit for bit.
 template <class Ops>
 void multi_scan_and_optimize(const std::vector<typename Ops::Solver>& solvers, const double* freq, size_t n, uint64_t ulp,
                              storm_bracket* out, size_t cap, size_t* n_out, int* had_invalid, double* det_out,
-                             uint64_t* index_out) {
+                             uint64_t* index_out, bool deal = true) {
   if (ulp == 0) fail(STORM_ERR_INVALID_ARGUMENT, "ulp precision must be >= 1");
   const size_t D = solvers.size();
+  auto scan = [&](typename Ops::Solver s, const double* f, size_t m, storm_bracket* br, size_t room, size_t* found, int* invalid,
+                  double* dets, uint64_t* idx) {
+    return deal ? Ops::scan_brackets(s, f, m, br, room, found, invalid, dets, idx)
+                : Ops::scan_and_optimize(s, f, m, ulp, br, room, found, invalid, dets, idx);
+  };
   // 1. every device scans its slice (+1 halo point) and filters its own adjacent pairs
   struct Part { size_t lo = 0; std::vector<storm_bracket> br; std::vector<uint64_t> idx; std::vector<double> det; int invalid = 0; };
   std::vector<Part> parts(D);
@@ -86,13 +96,11 @@ void multi_scan_and_optimize(const std::vector<typename Ops::Solver>& solvers, c
     p.br.resize(room); p.idx.resize(room);
     if (det_out) p.det.resize(m);
     size_t found = 0;
-    int rc = Ops::scan_brackets(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid,
-                                det_out ? p.det.data() : nullptr, p.idx.data());
+    int rc = scan(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid, det_out ? p.det.data() : nullptr, p.idx.data());
     if (rc == STORM_ERR_CAPACITY && room < m) {
       room = m;
       p.br.resize(room); p.idx.resize(room);
-      rc = Ops::scan_brackets(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid,
-                              det_out ? p.det.data() : nullptr, p.idx.data());
+      rc = scan(solvers[k], freq + lo, m, p.br.data(), room, &found, &p.invalid, det_out ? p.det.data() : nullptr, p.idx.data());
     }
     p.br.resize(rc == STORM_OK ? found : 0); p.idx.resize(rc == STORM_OK ? found : 0);
     if (rc == STORM_OK && det_out) std::memcpy(det_out + lo, p.det.data(), (hi - lo) * sizeof(double));  // owned points only
@@ -109,6 +117,13 @@ void multi_scan_and_optimize(const std::vector<typename Ops::Solver>& solvers, c
   if (had_invalid) *had_invalid = invalid;
   *n_out = all.size();
   if (all.size() > cap) fail(STORM_ERR_CAPACITY, "bracket output buffer too small");
+  if (!deal) {  // refined where they were found
+    for (size_t j = 0; j < all.size(); ++j) {
+      out[j] = all[j];
+      if (index_out) index_out[j] = idx[j];
+    }
+    return;
+  }
   // 3. the deal: bracket j goes to device j mod D
   std::vector<std::vector<storm_bracket>> share(D);
   for (size_t j = 0; j < all.size(); ++j) share[j % D].push_back(all[j]);

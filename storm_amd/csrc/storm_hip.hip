@@ -1828,6 +1828,7 @@ struct storm_multi {
   std::vector<storm_solver*> solvers;
   std::vector<int> devices;
   std::mutex mu;
+  bool deal = false;   // option "deal": 1 = brackets dealt cyclically over the devices for refinement (hostlogic/multi.hpp)
 };
 
 namespace {
@@ -1839,6 +1840,10 @@ struct SolverOps {
     return storm_scan_brackets(s, freq, n, out, cap, n_out, invalid, det_out, index_out);
   }
   static int optimize_brackets(Solver s, storm_bracket* br, size_t n, uint64_t ulp) { return storm_optimize_brackets(s, br, n, ulp); }
+  static int scan_and_optimize(Solver s, const double* freq, size_t n, uint64_t ulp, storm_bracket* out, size_t cap, size_t* n_out,
+                               int* invalid, double* det_out, uint64_t* index_out) {
+    return storm_scan_and_optimize(s, freq, n, ulp, out, cap, n_out, invalid, det_out, index_out);
+  }
   static int eigenvector_batch(Solver s, const double* freq, size_t n, double* det_out, double* vec_out) {
     return storm_eigenvector_batch(s, freq, n, det_out, vec_out);
   }
@@ -1894,6 +1899,11 @@ int storm_multi_set_option(storm_multi* q, const char* key, int64_t value) {
   return guarded([&] {
     if (!q) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lock(q->mu);
+    if (key && std::string(key) == "deal") {
+      if (value != 0 && value != 1) fail(STORM_ERR_INVALID_ARGUMENT, "deal must be 0 (refined where found) or 1 (dealt cyclically)");
+      q->deal = value != 0;
+      return;
+    }
     for (storm_solver* s : q->solvers) {
       const int rc = storm_solver_set_option(s, key, value);
       if (rc != STORM_OK) fail(rc, g_error);
@@ -1924,7 +1934,7 @@ int storm_multi_scan_and_optimize(storm_multi* q, const double* freq, size_t n, 
   return guarded([&] {
     if (!q || !n_out || (n && !freq) || (cap && !out)) fail(STORM_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lock(q->mu);
-    multi_scan_and_optimize<SolverOps>(q->solvers, freq, n, ulp, out, cap, n_out, had_invalid, det_out, index_out);
+    multi_scan_and_optimize<SolverOps>(q->solvers, freq, n, ulp, out, cap, n_out, had_invalid, det_out, index_out, q->deal);
   });
 }
 

@@ -263,6 +263,11 @@ struct ToyOps {
       b[k] = storm_bracket{br[k].lower.x, br[k].lower.f, br[k].upper.x, br[k].upper.f, br[k].root, br[k].evals};
     return STORM_OK;
   }
+  static int scan_and_optimize(Solver s, const double* freq, size_t n, uint64_t ulp, storm_bracket* out, size_t cap, size_t* n_out,
+                               int* invalid, double* det_out, uint64_t* index_out) {
+    const int rc = scan_brackets(s, freq, n, out, cap, n_out, invalid, det_out, index_out);
+    return rc != STORM_OK ? rc : optimize_brackets(s, out, *n_out, ulp);
+  }
   static int eigenvector_batch(Solver s, const double* freq, size_t n, double* det_out, double* vec_out) {
     if (s->fail_in == 3) { toy_error = "toy eigenvector failure"; return STORM_ERR_SINGULAR; }
     const size_t len = (s->n_int + 1) * 4;
@@ -286,22 +291,24 @@ static void multi_unit(size_t n, size_t D, uint64_t ulp, double wiggle = 1.0) {
   std::vector<ToySolver> devs(D, one);
   std::vector<ToySolver*> ptr1{&one}, ptrD;
   for (auto& d : devs) ptrD.push_back(&d);
-  auto run = [&](const std::vector<ToySolver*>& sv, std::vector<storm_bracket>& out, std::vector<uint64_t>& idx, std::vector<double>& det, int& inv) {
+  auto run = [&](const std::vector<ToySolver*>& sv, bool deal, std::vector<storm_bracket>& out, std::vector<uint64_t>& idx, std::vector<double>& det, int& inv) {
     out.assign(n ? n : 1, storm_bracket{}); idx.assign(n ? n : 1, 0); det.assign(n, -7.0);
     size_t found = 0;
-    multi_scan_and_optimize<ToyOps>(sv, f.data(), n, ulp, out.data(), out.size(), &found, &inv, det.data(), idx.data());
+    multi_scan_and_optimize<ToyOps>(sv, f.data(), n, ulp, out.data(), out.size(), &found, &inv, det.data(), idx.data(), deal);
     out.resize(found); idx.resize(found);
   };
   std::vector<storm_bracket> a, b;
   std::vector<uint64_t> ia, ib;
   std::vector<double> da, db;
   int inva = 0, invb = 0;
-  run(ptr1, a, ia, da, inva);
-  run(ptrD, b, ib, db, invb);
-  CHECK(a.size() == b.size() && ia == ib && inva == invb);
-  for (size_t k = 0; k < a.size(); ++k)
-    CHECK(same_bits(a[k].root, b[k].root) && same_bits(a[k].lo_x, b[k].lo_x) && same_bits(a[k].hi_f, b[k].hi_f) && a[k].evals == b[k].evals);
-  for (size_t i = 0; i < n; ++i) CHECK(same_bits(da[i], db[i]));
+  run(ptr1, true, a, ia, da, inva);
+  for (bool deal : {true, false}) {   // dealt cyclically | refined where found: the one-device result either way
+    run(ptrD, deal, b, ib, db, invb);
+    CHECK(a.size() == b.size() && ia == ib && inva == invb);
+    for (size_t k = 0; k < a.size(); ++k)
+      CHECK(same_bits(a[k].root, b[k].root) && same_bits(a[k].lo_x, b[k].lo_x) && same_bits(a[k].hi_f, b[k].hi_f) && a[k].evals == b[k].evals);
+    for (size_t i = 0; i < n; ++i) CHECK(same_bits(da[i], db[i]));
+  }
   if (!a.empty()) {
     std::vector<double> roots(a.size()), d1(a.size()), d2(a.size()), v1(a.size() * 38 * 4), v2(a.size() * 38 * 4);
     for (size_t k = 0; k < a.size(); ++k) roots[k] = a[k].root;
@@ -324,7 +331,7 @@ static void multi_errors() {
     size_t found = 0;
     int inv = 0;
     try {
-      multi_scan_and_optimize<ToyOps>(ptr, f.data(), f.size(), 1, out.data(), out.size(), &found, &inv, nullptr, idx.data());
+      multi_scan_and_optimize<ToyOps>(ptr, f.data(), f.size(), 1, out.data(), out.size(), &found, &inv, nullptr, idx.data(), where != 2);
       CHECK(where == 3);
       std::vector<double> d(found), v(found * 40);
       std::vector<double> roots(found);

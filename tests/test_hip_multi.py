@@ -38,8 +38,10 @@ def test_multi_equals_single_handle(oracle, oracle_models, scheme, ell, n):
     rdet, rvec = one.eigenvector(roots) if roots.size else (np.empty(0), np.empty((0, (o.n_int + 1) * 4)))
     oref, odets, _ = o.scan_and_optimize(f, ulp, threads=16)
     assert same(rdets, odets) and [b["root"] for b in ref] == [b["root"] for b in oref]
-    for devices in device_lists():
+    # both protocols (hostlogic/multi.hpp): brackets refined where they were found (default) and dealt cyclically ("deal" = 1)
+    for devices, deal in [(d, k) for d in device_lists() for k in (0, 1)]:
         multi = storm_amd.HipMulti(o.scheme, o.ell, o.m, o.system(), o.n_int, o.p, devices)
+        multi.set_option("deal", deal)
         got, gdets, ginv = multi.scan_and_optimize(f, ulp)
         assert same(gdets, rdets) and ginv == rinv, devices
         assert [b["index"] for b in got] == [b["index"] for b in ref], devices
