@@ -309,7 +309,7 @@ PDEV void coupling_matrix_body(const CouplingArgs& a, unsigned tile_l, unsigned 
     __syncthreads();
     if (grp == 0) {
       const size_t mm2 = M * M;
-      double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * kCouplingMatrices * mm2 : a.out;
+      double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * a.partial_stride : a.out;
       const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
       const double F = a.freq[rj >= 0 ? rj : 0];
       bool ok = true;
@@ -517,7 +517,7 @@ PDEV void coupling_matrix32_body(const CouplingArgs& a, unsigned tile_l, unsigne
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the grid's end land in this workgroup's LDS
   if (!exists) return;
   const size_t mm2 = M * M;
-  double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * kCouplingMatrices * mm2 : a.out;
+  double* __restrict__ out = a.n_split > 1 ? a.partial + size_t(piece) * a.partial_stride : a.out;
   const int rj = a.order[r0 + (size_t)(lane & 15)];        // the caller's indices; -1: padding, nothing to store
   const double F = a.freq[rj >= 0 ? rj : 0];
   bool ok = true;
@@ -897,16 +897,18 @@ __global__ __launch_bounds__(256) void coupling_pieces_kernel(const double* __re
   if (__syncthreads_or(!ok) && threadIdx.x == 0) atomicOr(flags, 1);
 }
 // several problems: problem p runs on XCD p % 8 (its modes are read by no other problem), per_problem workgroups each
+// (`base` workgroups per piece of the grid, the pieces one after the other: base is a multiple of 8)
 template <int TILE>
 __global__ __launch_bounds__(256, 2) void coupling_matrix_batch_kernel(const CouplingArgs* __restrict__ table, unsigned n_problems,
-                                                                       unsigned per_problem) {
-  const unsigned xcd = blockIdx.x % kCpXcds, k = blockIdx.x / kCpXcds;
+                                                                       unsigned per_problem, unsigned base) {
+  const unsigned piece = blockIdx.x / base, b = blockIdx.x % base;
+  const unsigned xcd = b % kCpXcds, k = b / kCpXcds;
   const unsigned p = (k / per_problem) * kCpXcds + xcd;
   if (p >= n_problems) return;
   const CouplingArgs a = table[p];
   unsigned tl, tr;
   if (!cp_tile_of(0, k % per_problem, 1, (unsigned)((a.n_pad + TILE - 1) / TILE), tl, tr)) return;
-  coupling_matrix_dispatch<TILE>(a, tl, tr, 0);
+  coupling_matrix_dispatch<TILE>(a, tl, tr, piece);
 }
 // 32 x 32 tiles from this many workgroups on (one per CU and a few more): below, the 16 x 16 walk's four times as many
 // smaller workgroups fill the chip better.  0 < `force` = 16 or 32 overrides (option "coupling_matrix_tile").
@@ -922,15 +924,16 @@ inline bool cp_use_tiles32(size_t tiles32_total, int force) {
 // Workgroups of the matrix-pipe walks that the chip holds at once: 32 x 32 tiles 2 per CU (208 registers per lane), 16 x 16
 // tiles 3 per CU (168 registers; 33 KB of LDS each).
 constexpr unsigned kCpSlots32 = 2 * 256, kCpSlots16 = 3 * 256;
-// Pieces of the grid per tile: the fewest that make (tiles x pieces) at least six rounds over the `slots` resident
-// workgroups -- tiles differ in cost (a tile of degrees more than 2 apart takes 2 of the 21 instructions), so what evens the
-// chip out is many more workgroups than slots, not a whole number of rounds -- capped at 32 and at pieces of 24 chunks (192
-// points), below which the ring's fill (about five chunks' worth) starts to show.  Measured, tile 32
-// (profiles/r03_coupling_split_sweep.txt): M = 80 2.15 -> 0.21 ms (32 pieces), 240: 2.16 -> 0.70 (32), 512: 3.39 -> 2.04 (6)
-// | 2.08 (16), 1024: 8.34 -> 6.99 (3), 2048: 26.4 -> 25.6 (3) | 26.6 (16).
+// Pieces of the grid per tile: the fewest that make (tiles x pieces) at least twelve rounds over the `slots` resident
+// workgroups -- tiles differ in cost (a tile of degrees more than 2 apart takes 2 of the 21 instructions) and a launch ends
+// with the chip waiting for its last workgroups, so what evens it out is many more, shorter workgroups than slots, not a
+// whole number of rounds -- capped at 32 and at pieces of 24 chunks (192 points): the ring's fill costs about five chunks'
+// worth per piece.  Measured, tile 32, one problem (profiles/r03_coupling_split_sweep.txt): M = 80 2.15 -> 0.21 ms (32
+// pieces), 240: 2.16 -> 0.70 (32), 512: 3.39 -> 2.04 (6) | 2.08 (16), 1024: 8.34 -> 6.99 (3 or 6), 2048: 26.4 -> 25.6 (3) |
+// 26.3 (2).
 inline unsigned cp_pieces(size_t tiles, unsigned slots, size_t n_chunks) {
   const size_t most = std::max<size_t>(1, std::min<size_t>(32, n_chunks / 24));
-  const size_t want = (6 * size_t(slots) + tiles - 1) / std::max<size_t>(tiles, 1);
+  const size_t want = (12 * size_t(slots) + tiles - 1) / std::max<size_t>(tiles, 1);
   return (unsigned)std::min(most, std::max<size_t>(want, 1));
 }
 }  // namespace STORM_NS
@@ -947,12 +950,25 @@ CouplingPlan plan_coupling_matrix(size_t n_pad, size_t n_pts, int matrix_tile, i
   if (split > 0) plan.n_split = (unsigned)std::min<size_t>(size_t(split), n_chunks);
   return plan;
 }
+// ... and for n_problems problems of at most max_pad positions in one launch (tile: as launch_coupling_batch chose before
+// there were pieces; pieces: the same twelve-rounds rule over all problems' tiles)
+CouplingPlan plan_coupling_batch(size_t max_pad, size_t n_problems, size_t n_pts, int matrix_tile, int split) {
+  using namespace storm_fast;
+  const size_t t16 = max_pad / 16, t32 = (max_pad + 31) / 32;
+  const size_t n_chunks = n_pts > 1 ? (n_pts - 1 + kCpChunk - 1) / kCpChunk : 1;
+  CouplingPlan plan;
+  plan.tile = cp_use_tiles32(t32 * t32 * n_problems, matrix_tile) ? 32 : 16;
+  plan.n_split = plan.tile == 32 ? cp_pieces(t32 * t32 * n_problems, kCpSlots32, n_chunks) : cp_pieces(t16 * t16 * n_problems, kCpSlots16, n_chunks);
+  if (split > 0) plan.n_split = (unsigned)std::min<size_t>(size_t(split), n_chunks);
+  return plan;
+}
 }  // namespace storm
 namespace STORM_NS {
 #endif
 
 hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts,
-                                 hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile) {
+                                 hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile,
+                                 unsigned n_split, const double* partial, double* out_all, size_t out_total, int* flags) {
   if (n_problems == 0 || max_modes == 0) return hipSuccess;
   if (tile != 8 && tile != 16) return hipErrorInvalidValue;
   const unsigned tiles = (unsigned)((max_modes + tile - 1) / tile);
@@ -972,18 +988,21 @@ hipError_t launch_coupling_batch(const CouplingArgs* table, size_t n_problems, s
     const unsigned ptiles = (unsigned)(max_pad / 16), ptiles32 = (unsigned)((max_pad + 31) / 32);
     if (ptiles > 65535) return hipErrorInvalidValue;
     const unsigned rounds = (unsigned)((n_problems + kCpXcds - 1) / kCpXcds);   // problems per XCD
-    if (cp_use_tiles32(size_t(ptiles32) * ptiles32 * n_problems, matrix_tile)) {
-      const unsigned per = cp_per_problem(ptiles32);
-      coupling_matrix_batch_kernel<32><<<dim3(rounds * per * kCpXcds, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per);
-    } else {
-      const unsigned per = cp_per_problem(ptiles);
-      if (size_t(rounds) * per * kCpXcds > 0x7fffffffu) return hipErrorInvalidValue;
-      coupling_matrix_batch_kernel<16><<<dim3(rounds * per * kCpXcds, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per);
-    }
+    const size_t n_chunks = (n_pts - 1 + kCpChunk - 1) / kCpChunk;
+    if (n_split == 0 || n_split > n_chunks || (n_split > 1 && (!partial || !out_all || !flags))) return hipErrorInvalidValue;
+    const bool t32 = cp_use_tiles32(size_t(ptiles32) * ptiles32 * n_problems, matrix_tile);
+    const unsigned per = cp_per_problem(t32 ? ptiles32 : ptiles);
+    if (size_t(rounds) * per * kCpXcds * n_split > 0x7fffffffu) return hipErrorInvalidValue;
+    const unsigned base = rounds * per * kCpXcds;
+    if (t32) coupling_matrix_batch_kernel<32><<<dim3(base * n_split, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per, base);
+    else coupling_matrix_batch_kernel<16><<<dim3(base * n_split, 1, 1), 256, 0, stream>>>(table, (unsigned)n_problems, per, base);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess || n_split == 1) return e;
+    coupling_pieces_kernel<<<(unsigned)((out_total + 255) / 256), 256, 0, stream>>>(partial, n_split, out_total, out_all, flags);
     return hipGetLastError();
   }
 #else
-  (void)max_pad; (void)matrix_tile;
+  (void)max_pad; (void)matrix_tile; (void)n_split; (void)partial; (void)out_all; (void)out_total; (void)flags;
 #endif
   if (tile == 8) coupling_batch_kernel<8><<<dim3(tiles, tiles, (unsigned)n_problems), 64, 0, stream>>>(table);
   else coupling_batch_kernel<16><<<dim3(tiles, tiles, (unsigned)n_problems), 256, 0, stream>>>(table);

@@ -112,12 +112,14 @@ struct CouplingArgs {
   // leaves a mostly empty last round (M = 1024: 1089 tiles on 512 slots = 2.13 rounds paid as 3).
   unsigned n_split = 1;
   double* partial = nullptr;
+  size_t partial_stride = 0;   // doubles from one piece's block to the next (one problem: 6 n_modes^2; a batch: all problems' outputs)
 };
 
 // Tile (16 or 32) and number of pieces of the matrix-pipe walk for one problem of n_pad ordered positions on n_pts grid
 // points; matrix_tile / split: 0 = automatic, else forced (options "coupling_matrix_tile", "coupling_split").
 struct CouplingPlan { int tile; unsigned n_split; };
 CouplingPlan plan_coupling_matrix(size_t n_pad, size_t n_pts, int matrix_tile, int split);
+CouplingPlan plan_coupling_batch(size_t max_pad, size_t n_problems, size_t n_pts, int matrix_tile, int split);
 
 // dst[k][0 .. row_elems) = src[index[k]][0 .. row_elems) for k < n (device arrays): picks the post-processing fields of
 // a subset of modes out of a larger resident set without leaving HBM.
@@ -132,12 +134,15 @@ hipError_t launch_gather_rows(const double* src, const long long* index, size_t 
 // (common) grid size of the entries; with_tame: some entry has a `tame` array to fill first.  tile: modes per side of a
 // workgroup's tile of pairs, 8 (one wave) or 16 (four waves sharing the staged fields).  max_pad: the largest n_pad of
 // the table if EVERY entry carries an ordered mode list (FMA build: the matrix-pipe walk takes the launch), else 0;
-// matrix_tile: 0 = automatic, 16 or 32 = that tile of the matrix-pipe walk.
+// matrix_tile: 0 = automatic, 16 or 32 = that tile of the matrix-pipe walk.  n_split > 1 (matrix-pipe walk only; every entry
+// carries n_split, its `partial` and partial_stride = out_total): the pieces are added into out_all[0 .. out_total) -- the
+// entries' outputs, back to back -- by a second launch; plan_coupling_batch gives tile and pieces.
 #define STORM_DECL_COUPLING(ns)                                                                                         \
   namespace ns {                                                                                                        \
   hipError_t launch_coupling(const storm::CouplingArgs& args, int tile, int matrix_tile);                               \
   hipError_t launch_coupling_batch(const storm::CouplingArgs* table, size_t n_problems, size_t max_modes, size_t n_pts, \
-                                   hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile);      \
+                                   hipStream_t stream, bool with_tame, int tile, size_t max_pad, int matrix_tile,       \
+                                   unsigned n_split, const double* partial, double* out_all, size_t out_total, int* flags); \
   }
 STORM_DECL_COUPLING(storm)
 STORM_DECL_COUPLING(storm_fast)

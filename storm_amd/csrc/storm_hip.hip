@@ -1723,6 +1723,7 @@ void coupling_run(storm_postproc* p, size_t n, const uint64_t* ell, const double
       if (plan.n_split > 1) {
         p->d_partial.reserve(size_t(plan.n_split) * kCouplingMatrices * n * n, p->stream);
         a.partial = p->d_partial.p;
+        a.partial_stride = size_t(kCouplingMatrices) * n * n;
       }
     }
     if (coupling_has_sparse_pair(consts)) {
@@ -1982,6 +1983,7 @@ struct storm_sweep {
   // resident_at[i] = row of the mode the caller passed i-th.  Any other modes call drops them.
   std::vector<long long> resident_at;
   DevBuf<double> d_cp;        // batched coupling integrals: weights, consts, frequencies, results of every problem
+  DevBuf<double> d_cp_partial;  // ... and the sums of the pieces of a split walk, [piece][results of every problem]
   DevBuf<long long> d_cp_idx; // rows of the resident fields
   DevBuf<int> d_cp_ell, d_cp_flags, d_cp_order;
   DevBuf<CouplingArgs> d_cp_table;
@@ -1996,7 +1998,7 @@ struct storm_sweep {
   PinnedBuf h_growth;
   int segments = 0;           // option "segments": -1 = never, 0 = automatic (FMA build only)
   double seg_growth_max = 0x1p24;
-  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0, cp_matrix = 1, cp_matrix_tile = 0;
+  int arith = 0, hex_lanes = 0, hex_rounds = 1, eigen_layout = 0, cp_tile = 0, cp_matrix = 1, cp_matrix_tile = 0, cp_split = 0;
   // (A sweep refines its brackets with the host state machine, set_refine: it evaluates only the brackets still open.  A
   // device version over all bracket slots every round existed in round 2 behind an option and was removed in round 3: 64
   // systems x 300 frequencies, 1688 brackets, 7 rounds: 17.8 ms per scan on the host, 20.2 ms on the device -- the late rounds
@@ -2433,7 +2435,7 @@ void storm_sweep_destroy(storm_sweep* q) {
   if (q->sync_marker) (void)hipEventDestroy(q->sync_marker);
   q->tab.release(); q->d_table.release(); q->d_freq.release(); q->d_det.release(); q->d_steps.release(); q->d_upper.release();
   q->d_vec.release(); q->d_sys.release(); q->d_swaps.release(); q->d_flags.release(); q->d_terms.release(); q->d_scale.release();
-  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release(); q->d_cp_order.release();
+  q->d_fields.release(); q->d_nodes.release(); q->d_ids.release(); q->d_post_table.release(); q->d_cp.release(); q->d_cp_idx.release(); q->d_cp_ell.release(); q->d_cp_flags.release(); q->d_cp_order.release(); q->d_cp_partial.release();
   q->d_cp_table.release(); q->h_cp.release(); q->h_in.release(); q->h_out.release(); q->h_flags.release();
   q->d_partials.release(); q->d_seg_nodes.release(); q->d_growth.release(); q->d_table_red.release(); q->h_growth.release();
   (void)hipSetDevice(prev);
@@ -2463,6 +2465,9 @@ int storm_sweep_set_option(storm_sweep* q, const char* key, int64_t value) {
     } else if (k == "coupling_matrix_tile") {
       if (value != 0 && value != 16 && value != 32) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_matrix_tile must be 0 (auto), 16 or 32");
       q->cp_matrix_tile = int(value);
+    } else if (k == "coupling_split") {
+      if (value < 0 || value > 64) fail(STORM_ERR_INVALID_ARGUMENT, "coupling_split must be 0 (automatic) or 1..64 pieces");
+      q->cp_split = int(value);
     } else if (k == "segments") {
       if (value != 0 && value != -1) fail(STORM_ERR_INVALID_ARGUMENT, "segments must be 0 (automatic, FMA build only) or -1 (never)");
       q->segments = int(value);
@@ -2824,10 +2829,21 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
       q->d_cp_order.reserve(orders.size() + 1, st);
       hip_check(hipMemcpyAsync(q->d_cp_order.p, orders.data(), orders.size() * sizeof(int), hipMemcpyHostToDevice, st), "order H2D");
     }
+    // the matrix-pipe walk's tile and the pieces the grid is cut into per tile (a launch ends waiting for its last
+    // workgroups: many short ones instead of a few long ones); the pieces' sums go to d_cp_partial, [piece][all outputs]
+    storm::CouplingPlan plan{q->cp_matrix_tile, 1};
+    if (max_pad) {
+      plan = storm::plan_coupling_batch(max_pad, n_problems, np, q->cp_matrix_tile, q->cp_split);
+      if (plan.n_split > 1) q->d_cp_partial.reserve(size_t(plan.n_split) * out_total, st);
+    }
     for (size_t j = 0; j < n_problems; ++j) {
       const size_t n = offsets[j + 1] - offsets[j];
       CouplingArgs& a = table[j];
-      if (max_pad) { a.order = q->d_cp_order.p + ord_off[j]; a.n_pad = ord_off[j + 1] - ord_off[j]; }
+      if (max_pad) {
+        a.order = q->d_cp_order.p + ord_off[j]; a.n_pad = ord_off[j + 1] - ord_off[j];
+        a.n_split = plan.n_split;
+        if (plan.n_split > 1) { a.partial = q->d_cp_partial.p + out_at; a.partial_stride = out_total; }
+      }
       a.n_pts = np; a.n_modes = n; a.fields = q->d_fields.p; a.rows = q->d_cp_idx.p + offsets[j];
       a.freq = df + offsets[j]; a.ell_index = q->d_cp_ell.p + offsets[j];
       a.consts = dc + c_off[j]; a.n_ell = int(n_ell[j]); a.weights = dw + j * w_elems;
@@ -2846,7 +2862,8 @@ int storm_sweep_coupling_matrices_batch(storm_sweep* q, size_t n_problems, storm
     hip_check(hipMemsetAsync(q->d_cp_flags.p, 0, sizeof(int), st), "flags memset");
     hip_check((q->arith ? storm_fast::launch_coupling_batch : storm::launch_coupling_batch)(q->d_cp_table.p, n_problems,
                                                                                              max_modes, np, st, with_tame,
-                                                                                             q->cp_tile ? q->cp_tile : coupling_tile_auto(max_modes), max_pad, q->cp_matrix_tile),
+                                                                                             q->cp_tile ? q->cp_tile : coupling_tile_auto(max_modes), max_pad, plan.tile,
+                                                                                             plan.n_split, q->d_cp_partial.p, dout, out_total, q->d_cp_flags.p),
               "coupling launch");
     q->stats.launches += 1;
     // (the pageable sources above are staged by the runtime before the calls return; the pinned block is reused for the
