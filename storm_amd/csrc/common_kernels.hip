@@ -53,12 +53,14 @@ SDEV double chain_step(double acc, double2 lo, double2 hi) {
 // elimination runs on the renormalised product; with acc = 2^K acc' the discriminant is 2^(2K) times the one of acc'
 // (the two outer-boundary rows carry the factor: scale rows 2..5 by 2^-K, columns 4..7 by 2^K, the last two rows by
 // 2^-K).  Mathematically the reference's value; the pivot order may differ from the raw run's, so it agrees with the
-// raw discriminant to rounding, not bit for bit.
+// raw discriminant to rounding, not bit for bit.  every_step: renormalise after every step instead (the "steps" are segment
+// transfer matrices, each the product of a hundred step matrices and up to ~2^200 in magnitude: sixteen of them between
+// two renormalisations could overflow); the scalings are exact, so the result does not depend on where they happen.
 template <bool ELL0, bool SCALED>
 __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __restrict__ freq, size_t n,
                                                    const double* __restrict__ steps, double* __restrict__ det_out,
                                                    long long* __restrict__ exp_out, const SystemDev* __restrict__ table,
-                                                   const int* __restrict__ sys_index) {
+                                                   const int* __restrict__ sys_index, bool every_step) {
   __shared__ double sh[64];
   const int tid = threadIdx.x;
   const int sub = tid & 15;
@@ -95,12 +97,18 @@ __global__ __launch_bounds__(64) void chain_kernel(SystemDev s, const double* __
       cur = nxt;
       if (b + 1 < n_blocks) chain_load(nxt, rows, (b + 1) * kChainBlock);
 #pragma unroll
-      for (int u = 0; u < kChainBlock; ++u) acc = chain_step(acc, cur.lo[u], cur.hi[u]);
+      for (int u = 0; u < kChainBlock; ++u) {
+        acc = chain_step(acc, cur.lo[u], cur.hi[u]);
+        if (SCALED && every_step) renormalise();
+      }
       renormalise();
     }
     i = n_blocks * kChainBlock;
   }
-  for (; i < n_int; ++i) acc = chain_step(acc, rows[i * 8], rows[i * 8 + 1]);
+  for (; i < n_int; ++i) {
+    acc = chain_step(acc, rows[i * 8], rows[i * 8 + 1]);
+    if (SCALED && every_step) renormalise();
+  }
   renormalise();
   sh[tid] = acc;  // element (r, c) at group*16 + c*4 + r: column-major, as M4 wants it
   __syncthreads();
@@ -133,16 +141,16 @@ hipError_t launch_chain(const SystemDev& s, bool ell0, const double* freq, size_
                         double* det_out, hipStream_t stream, const SystemDev* table, const int* sys_index) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 3) / 4);
-  if (ell0) chain_kernel<true, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index);
-  else chain_kernel<false, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index);
+  if (ell0) chain_kernel<true, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index, false);
+  else chain_kernel<false, false><<<blocks, 64, 0, stream>>>(s, freq, n, steps, det_out, nullptr, table, sys_index, false);
   return hipGetLastError();
 }
 hipError_t launch_chain_scaled(const SystemDev& s, bool ell0, const double* freq, size_t n, const double* steps,
-                               double* mantissa_out, long long* exponent_out, hipStream_t stream) {
+                               double* mantissa_out, long long* exponent_out, hipStream_t stream, bool every_step) {
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 3) / 4);
-  if (ell0) chain_kernel<true, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr);
-  else chain_kernel<false, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr);
+  if (ell0) chain_kernel<true, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr, every_step);
+  else chain_kernel<false, true><<<blocks, 64, 0, stream>>>(s, freq, n, steps, mantissa_out, exponent_out, nullptr, nullptr, every_step);
   return hipGetLastError();
 }
 

@@ -25,7 +25,8 @@ inline size_t swap_blocks(size_t n) { return n < 2 ? 0 : (n - 1 + 1023) / 1024; 
                           double* det_out, hipStream_t stream, const storm::SystemDev* table = nullptr,           \
                           const int* sys_index = nullptr);                                                        \
   hipError_t launch_chain_scaled(const storm::SystemDev& s, bool ell0, const double* freq, size_t n,               \
-                                 const double* steps, double* mantissa_out, long long* exponent_out, hipStream_t stream); \
+                                 const double* steps, double* mantissa_out, long long* exponent_out, hipStream_t stream, \
+                                 bool every_step = false);                                                        \
   hipError_t launch_aos_copy(double* tab, size_t n_sys, size_t sys_elems, size_t stride, int p, hipStream_t stream); \
   hipError_t launch_swap_count(const double* det, size_t n, unsigned* block_count, int* flags, hipStream_t stream); \
   hipError_t launch_swap_offsets(unsigned* block_count, size_t n_blocks, hipStream_t stream);                      \

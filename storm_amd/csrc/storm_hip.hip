@@ -1083,7 +1083,71 @@ int storm_det_batch_device(storm_solver* s, const double* d_freq, size_t n, doub
 
 // The discriminant as mantissa * 2^exponent for n host frequencies (caller holds the handle's lock, device current): step
 // matrices staged in chunks of steps_bytes_max, chain_kernel<.., SCALED> over them.
+static void det_scaled_staged(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out);
+
+// FMA build: the same number through the segment path -- seg_product forms the transfer matrix of every (frequency,
+// segment of 128 intervals) pair with the fast kernels' arithmetic (a segment's product stays far inside f64: the raw
+// product of a whole grid needs ~1 bit per interval to overflow), then chain_kernel<.., SCALED> multiplies the segments'
+// matrices with a renormalisation after every one.  A whole-grid scaled scan then costs about what the raw scan costs
+// instead of staging 128 B per (frequency, interval).  A frequency whose value comes out non-finite (a segment that did
+// overflow, or a genuinely non-finite discriminant) is evaluated again through the staged path, which renormalises every
+// 16 intervals.  Not in the parity build (the segment path re-associates the ordered product).
+static bool det_scaled_segments(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
+  const size_t n_int = s->sys.n_int;
+  if (s->arith != 1 || s->segments < 0 || n_int < 64) return false;
+  hipStream_t st = s->stream;
+  const size_t len = s->segments > 0 ? (size_t(s->segments) + 15) / 16 * 16 : 128;
+  const size_t n_seg = (1 + (n_int - 1 + len - 1) / len + 3) / 4 * 4;   // (the first interval is a segment of its own: plan_segments)
+  if (n_seg > (size_t(1) << 24)) return false;
+  const size_t per_freq = n_seg * 16 * sizeof(double);
+  const size_t chunk = std::min<size_t>({n, std::max<size_t>(4, s->steps_bytes_max / per_freq / 4 * 4), ((size_t(1) << 31) - 1) * 4 / n_seg / 4 * 4});
+  s->d_freq.reserve(chunk, st); s->d_det.reserve(chunk, st);
+  s->d_bidx.reserve(chunk, st);  // (exponents: 8 bytes per frequency)
+  steps_acquire(s, st);
+  s->steps_user = nullptr;
+  s->d_partials.reserve(chunk * n_seg * 16, st);
+  SystemDev reduced = s->sys;
+  reduced.n_int = n_seg;
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t m = std::min(chunk, n - off);
+    hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
+    LaunchArgs a = make_args(s, s->d_freq.p, m, s->d_partials.p, st);
+    a.n_seg = int(n_seg); a.seg_len = int(len);
+    hip_check(g_launch_seg_product[s->arith][s->scheme](a), "seg_product launch");
+    hip_check(storm_fast::launch_chain_scaled(reduced, s->ell0, s->d_freq.p, m, s->d_partials.p, s->d_det.p,
+                                              reinterpret_cast<long long*>(s->d_bidx.p), st, true), "chain launch");
+    count_launch(s, 2);
+    hip_check(hipMemcpyAsync(mantissa_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, st), "mantissa D2H");
+    hip_check(hipMemcpyAsync(exponent_out + off, s->d_bidx.p, m * sizeof(int64_t), hipMemcpyDeviceToHost, st), "exponent D2H");
+    hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+    // (the singular-stage flag is looked at by the staged pass below if one is needed, else here)
+  }
+  s->stats.det_evals += n;
+  std::vector<size_t> again;
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(mantissa_out[i])) again.push_back(i);
+  if (!again.empty()) {
+    std::vector<double> f(again.size()), m2(again.size());
+    std::vector<int64_t> e2(again.size());
+    for (size_t k = 0; k < again.size(); ++k) f[k] = freq[again[k]];
+    // a segment that overflowed may have raised the singular-stage flag on the way (inf - inf in a stage solve): the staged
+    // pass decides
+    hip_check(hipMemsetAsync(s->d_flags.p, 0, sizeof(int), st), "flags memset");
+    det_scaled_staged(s, f.data(), f.size(), m2.data(), e2.data());
+    s->stats.det_evals -= again.size();
+    for (size_t k = 0; k < again.size(); ++k) { mantissa_out[again[k]] = m2[k]; exponent_out[again[k]] = e2[k]; }
+  } else {
+    check_flags(s);
+  }
+  return true;
+}
+
 static void det_scaled_locked(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
+  if (det_scaled_segments(s, freq, n, mantissa_out, exponent_out)) return;
+  det_scaled_staged(s, freq, n, mantissa_out, exponent_out);
+}
+
+static void det_scaled_staged(storm_solver* s, const double* freq, size_t n, double* mantissa_out, int64_t* exponent_out) {
   hipStream_t st = s->stream;
   const size_t n_int = s->sys.n_int;
   const size_t per_freq = std::max<size_t>(1, n_int) * 16 * sizeof(double);
@@ -1098,7 +1162,7 @@ static void det_scaled_locked(storm_solver* s, const double* freq, size_t n, dou
     hip_check(hipMemcpyAsync(s->d_freq.p, freq + off, m * sizeof(double), hipMemcpyHostToDevice, st), "freq H2D");
     hip_check(g_launch_build[s->arith][s->scheme](make_args(s, s->d_freq.p, m, s->d_steps.p, st)), "build_steps launch");
     hip_check((s->arith ? storm_fast::launch_chain_scaled : storm::launch_chain_scaled)(
-                  s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_det.p, reinterpret_cast<long long*>(s->d_bidx.p), st),
+                  s->sys, s->ell0, s->d_freq.p, m, s->d_steps.p, s->d_det.p, reinterpret_cast<long long*>(s->d_bidx.p), st, false),
               "chain launch");
     count_launch(s, 2);
     hip_check(hipMemcpyAsync(mantissa_out + off, s->d_det.p, m * sizeof(double), hipMemcpyDeviceToHost, st), "mantissa D2H");

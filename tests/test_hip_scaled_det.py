@@ -120,8 +120,12 @@ def test_scaled_scan_finds_the_raw_scans_modes_where_the_raw_product_is_finite(o
         h.optimize_brackets(wrong, ulp)
 
 
-def test_scaled_scan_brackets_where_the_raw_product_overflows():
-    """The synthetic system of test_scaled_survives_overflow_of_the_raw_product: every raw discriminant is +-inf, the raw
+@pytest.mark.parametrize("arith,segments", [(0, 0), (1, 0), (1, 1488)])
+def test_scaled_scan_brackets_where_the_raw_product_overflows(arith, segments):
+    """(arith 1: the FMA build takes the segment path -- transfer matrices of 128-interval segments from the fast kernels,
+    then the scaled chain over the segments; segments = 1488 makes one segment of nearly the whole grid, whose product
+    overflows: every frequency must then come back through the staged path with the same answers.)
+    The synthetic system of test_scaled_survives_overflow_of_the_raw_product: every raw discriminant is +-inf, the raw
     scan drops every pair (the reference: `invalid numbers`, src/dynamic_interface.rs:130-137) and finds nothing.  With
     scaled_scan the sign changes of the numpy restatement are found at the same grid indices and the refined roots sit
     where that restatement changes sign."""
@@ -132,6 +136,9 @@ def test_scaled_scan_brackets_where_the_raw_product_overflows():
     sys_ = dict(u=np.full(n_int, u), v_gamma=np.full(n_int, vg), a_star=np.full(n_int, a_s), c1=np.full(n_int, c1),
                 rot=np.zeros(n_int), delta_over_x=np.full(n_int, dx), inner_c1=c1, inner_rot=0.0, outer_u=outer_u)
     h = storm_amd.HipSolver("colloc2", 0, 0, sys_, n_int, 1)
+    h.set_option("arithmetic", arith)
+    if segments:
+        h.set_option("segments", segments)
     f = np.linspace(4.45, 4.6, 61)
     ulp = storm_amd.relative_to_ulp(1e-9)
     raw, raw_dets, raw_inv = h.scan_and_optimize(f, ulp)
