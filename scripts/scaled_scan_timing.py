@@ -1,3 +1,4 @@
+"""Raw scan against scaled scan (option scaled_scan) on the bench headline grid, both builds: wall time per scan, bracket\nindex lists, largest root difference."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo")
