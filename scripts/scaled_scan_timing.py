@@ -1,7 +1,8 @@
-"""Raw scan against scaled scan (option scaled_scan) on the bench headline grid, both builds: wall time per scan, bracket\nindex lists, largest root difference."""
+"""Raw scan against scaled scan (option scaled_scan) on the bench headline grid, both builds: wall time per scan, bracket
+index lists, largest root difference."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import storm_amd
 from storm_amd import host, ffi
 model = host.Model.construct_polytrope(3.0, 5.0 / 3.0, 6.89684861937 / 9999.0)
