@@ -534,6 +534,24 @@ def secondary_legs(host, ffi, D, torch, ulp, local_rank):
             "ms_per_scan": round(dt * 1e3, 3), "modes": len(r0),
             "evals_per_s": (N_FREQ + sum(b["evals"] for b in r0)) * e0.n_int / dt}
     legs["polytrope0"]["workload"] = "Polytrope0{5/3} on linspace(0,1,10^4), ell=2, Colloc4, linspace(1,25,10^5), 1e-8, + eigenvectors"
+    # ---- the same scan bracketing on the scaled discriminant (option scaled_scan: mantissa x 2^exponent), FMA build
+    h0.set_option("arithmetic", 1)
+    raw0, _, _ = h0.scan_and_optimize(f0, ulp, cap=8192, want_dets=False)
+    t0 = time.perf_counter()
+    h0.scan_and_optimize(f0, ulp, cap=8192, want_dets=False)
+    t_raw = time.perf_counter() - t0
+    h0.set_option("scaled_scan", 1)
+    sc0, _, _ = h0.scan_and_optimize(f0, ulp, cap=8192, want_dets=False)
+    t0 = time.perf_counter()
+    h0.scan_and_optimize(f0, ulp, cap=8192, want_dets=False)
+    t_sc = time.perf_counter() - t0
+    h0.set_option("scaled_scan", 0)
+    same = [b["index"] for b in raw0] == [b["index"] for b in sc0]
+    legs["scaled_scan"] = {"workload": "the Polytrope0 scan above without eigenvectors, FMA build",
+                           "raw_ms_per_scan": round(t_raw * 1e3, 3), "scaled_ms_per_scan": round(t_sc * 1e3, 3),
+                           "bracket_indices_equal": same,
+                           "max_root_rel_diff": (max(abs(a["root"] - b["root"]) / abs(a["root"]) for a, b in zip(raw0, sc0))
+                                                 if same and raw0 else None)}
     del h0, e0
 
     # ---- BASELINE config 2: tams, ell = 1..3 x {Magnus6, Colloc8}, 10^4 frequencies, six handles on six threads

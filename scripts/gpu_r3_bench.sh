@@ -14,7 +14,7 @@ print("cpu", d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_base
 s=d['secondary']
 print("cfg2", {k:(v['ms_per_step'], v['roofline']['frac']) for k,v in s['config2'].items() if isinstance(v,dict)})
 print("coupling", {k:(v['avg_launch_ms'], v['frac'], v['reference_equivalent']['ratio_to_peak']) for k,v in s['coupling_integrals'].items() if isinstance(v,dict) and 'frac' in v})
-print("sweep", s['rotation_sweep']['ms_per_scan'], "batch", s.get('batch_pipeline'))
+print("sweep", s["rotation_sweep"]["ms_per_scan"], "scaled", s.get("scaled_scan"), "batch", s.get("batch_pipeline"))
 print("phases", d['phases']['max_over_ranks'], "multi", d['multi_in_library'])
 PY
 cd /tmp && export TMPDIR=/tmp
